@@ -1,0 +1,181 @@
+/*
+ * jpegenc_amd.h -- C-ABI of the MI355X (gfx950) baseline-JPEG encode/decode library.
+ *
+ * This is the boundary the C++ host classes (namespace jpeg: Encoder,
+ * BaselineEncoder and their components) call through, and what any other host
+ * language would bind.  Plain pointers and sizes only; no exceptions cross it.
+ * Every function returns JEA_OK (0) or a JEA_ERR_* code; jea_last_error() gives
+ * the text, which for the decode-side checks is the reference's own message.
+ *
+ * The functions replace these pieces of the reference (paths relative to the
+ * reference root):
+ *   whole encode   jpeg/src/encoder.cpp:14-42   (Encoder::encode)
+ *   whole decode   jpeg/src/encoder.cpp:44-71   (Encoder::decode)
+ *   stage entry points: see each declaration.
+ *
+ * Image layout everywhere: RGB8, row-major, top-down, tightly packed
+ * (jpeg/inc/bitmap_image.hpp:20-25: m_imageData[y * m_width + x] = {r,g,b}).
+ * Coefficient layout: int16, [image][mcu][channel][64] in zig-zag order, MCUs in
+ * raster order, channels Y, Cb, Cr -- the order the reference entropy-codes them
+ * in (encoder.cpp:21-27).
+ * Quantisation tables: 64 x uint16, natural (row-major) order, as held by the
+ * reference's Quantiser (jpeg/inc/quantiser.hpp:24-25).
+ *
+ * Pointers named d_* are device (HIP) pointers on the context's GPU; pointers
+ * named h_* are host pointers.  A context owns one HIP stream and its scratch
+ * buffers and must be used from one thread at a time; distinct contexts are
+ * independent (one per GPU, or several per GPU).
+ */
+#ifndef JPEGENC_AMD_H_
+#define JPEGENC_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JEA_OK 0
+#define JEA_ERR_INVALID_ARG 1   /* null pointer, zero size, width/height out of 1..65535 */
+#define JEA_ERR_HIP 2           /* a HIP runtime call failed; text has the HIP error */
+#define JEA_ERR_CAPACITY 3      /* output (or scratch sized from it) too small */
+#define JEA_ERR_RANGE 4         /* coefficient outside the Huffman tables' categories */
+#define JEA_ERR_BAD_HEADER 5    /* decode: a header field check failed (encoder.cpp:140-283) */
+#define JEA_ERR_BAD_STREAM 6    /* decode: invalid Huffman code / run (entropy_encoder.cpp:776,826,842) */
+#define JEA_ERR_NO_EOI 7        /* decode: "Failed to find EOI marker" (encoder.cpp:63-65) */
+#define JEA_ERR_NO_DEVICE 8     /* no usable gfx950 device / library built without device code */
+
+#define JEA_HEADER_BYTES 607    /* SOI..SOS written by encoder.cpp:74-138 */
+
+typedef struct jea_ctx jea_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Creates a context on HIP device `device_id` with its own stream. */
+int jea_create(int device_id, jea_ctx** out_ctx);
+void jea_destroy(jea_ctx* ctx);
+/* Message of the last failing call on this context (or of jea_create when ctx is NULL). */
+const char* jea_last_error(const jea_ctx* ctx);
+/* Use a caller-owned hipStream_t for all following work (NULL = the context's own stream). */
+int jea_set_stream(jea_ctx* ctx, void* hip_stream);
+/* The hipStream_t the context launches on (so callers can record events on it). */
+void* jea_get_stream(jea_ctx* ctx);
+/* Blocks until all work enqueued on the context's stream has finished. */
+int jea_synchronize(jea_ctx* ctx);
+
+/* ---- tables (host-side helpers, no GPU work) -------------------------- */
+
+/* Quality -> tables, the arithmetic of Quantiser::Quantiser (quantiser.cpp:3-55). */
+void jea_quant_tables(int quality, uint16_t lum_q[64], uint16_t chr_q[64]);
+/* The fixed 607-byte header of encoder.cpp:74-138 (+ quantiser.cpp:87-102,
+ * entropy_encoder.cpp:636-694) for a width x height image. */
+void jea_write_header(uint8_t out[JEA_HEADER_BYTES], uint16_t width, uint16_t height,
+                      const uint16_t lum_q[64], const uint16_t chr_q[64]);
+/* Upper bound of one JPEG file: header + worst-case stuffed scan + pad + EOI. */
+size_t jea_max_jpeg_bytes(uint16_t width, uint16_t height);
+/* Header validation of Encoder::decodeHeader (encoder.cpp:140-283).  Returns
+ * JEA_OK or JEA_ERR_BAD_HEADER; `msg` (may be NULL) receives the reference's
+ * message for the first failing field; hdr_width/hdr_height the SOF0 fields. */
+int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uint16_t* hdr_height,
+                     const char** msg);
+
+/* ---- whole encode: Encoder::encode, encoder.cpp:14-42 ------------------ */
+
+/* Encodes `n_images` equally sized device-resident images in one pass and
+ * returns when the result is complete.  Image i is at d_rgb + i*3*width*height.
+ * JPEG file i (header, scan, EOI) is written to d_out + h_offsets[i] and is
+ * h_sizes[i] bytes long; files are packed back to back at 64-byte aligned
+ * offsets.  `out_capacity` bounds d_out; n_images * jea_max_jpeg_bytes() always
+ * suffices, less is fine when the images compress (JEA_ERR_CAPACITY otherwise). */
+int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                     const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
+                     uint64_t* h_offsets, uint64_t* h_sizes);
+
+/* Same work, asynchronous: enqueues on the context's stream and returns.
+ * d_offsets / d_sizes (n_images x uint64 each) and d_status (one int32: 0 or a
+ * JEA_ERR_* code) are device buffers filled by the kernels; read them after
+ * jea_synchronize() or from later work on the same stream. */
+int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                           const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out,
+                           size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
+
+/* One image held in host memory: copies it to the GPU, encodes, copies the file
+ * back.  This is what BaselineEncoder::encode(BitmapImageRGB const&, JPEGImage&)
+ * calls.  h_out must hold out_capacity bytes; *out_len receives the file size. */
+int jea_encode_host(jea_ctx* ctx, const uint8_t* h_rgb, uint16_t width, uint16_t height,
+                    const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* h_out, size_t out_capacity,
+                    size_t* out_len);
+
+/* ---- whole decode: Encoder::decode, encoder.cpp:44-71 ------------------ */
+
+/* Decodes n_images JPEG files produced by this encoder family (fixed header
+ * layout, Annex-K Huffman tables).  File i is d_jpeg + h_offsets[i], h_sizes[i]
+ * bytes.  As in the reference, the output dimensions are the caller's
+ * (JPEGImage::m_width/m_height, encoder.cpp:46), not the SOF0 fields, and the
+ * tables are the caller's, not the file's DQT (encoder.cpp:187-188).  Image i is
+ * written to d_rgb + i*3*width*height. */
+int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offsets, const uint64_t* h_sizes,
+                     size_t n_images, uint16_t width, uint16_t height, const uint16_t lum_q[64],
+                     const uint16_t chr_q[64], uint8_t* d_rgb);
+
+/* One file in host memory -> one image in host memory
+ * (BaselineEncoder::decode(JPEGImage, BitmapImageRGB&)). */
+int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t width, uint16_t height,
+                    const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* h_rgb);
+
+/* ---- stage entry points (device pointers; synchronous) ---------------- */
+
+/* Fused block fetch with edge replication + RGB->YCbCr + level shift + separable
+ * 8x8 forward DCT + quantise + zig-zag.  Replaces block_grid.cpp:8-58,
+ * colour_mapping.cpp:44-67, discrete_cosine_transform.cpp:3-6,13-19,77-124,
+ * quantiser.cpp:57-70, entropy_encoder.cpp:15-77.
+ * d_coefs: n_images * mcus * 3 * 64 int16. */
+int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                   const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs);
+
+/* Bit length of every block-channel ([image][mcu][channel] order) with the DC
+ * prediction chain of encoder.cpp:20 restarted per image.  Replaces
+ * entropy_encoder.cpp:94-120 and the length side of :715-765.
+ * d_lengths: n_images * mcus_per_image * 3 uint16. */
+int jea_block_bit_lengths(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
+                          uint16_t* d_lengths);
+
+/* Entropy-coded scan segments from coefficient blocks: Huffman coding
+ * (entropy_encoder.cpp:94-120, 696-765), MSB-first packing
+ * (bit_stream.cpp:44-81), byte stuffing (:127-134) and zero-bit padding
+ * (:101-105).  No header, no EOI.  Segment i is written to
+ * d_out + h_offsets[i] (64-byte aligned), h_sizes[i] bytes. */
+int jea_entropy_encode(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
+                       uint8_t* d_out, size_t out_capacity, uint64_t* h_offsets, uint64_t* h_sizes);
+
+/* Inverse of jea_entropy_encode on stuffed scan bytes that are followed by the
+ * EOI marker: unstuffing (bit_stream.cpp:136-147), Huffman decoding
+ * (entropy_encoder.cpp:703-712, 767-866), run-length removal including the
+ * dropped last entry (:122-144), DC chain.  Segment i starts at
+ * d_scan + h_offsets[i] and, with its 2-byte EOI, is h_sizes[i] bytes. */
+int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_offsets, const uint64_t* h_sizes,
+                       size_t n_images, size_t mcus_per_image, int16_t* d_coefs);
+
+/* De-zigzag + dequantise + separable 8x8 inverse DCT + level unshift +
+ * YCbCr->RGB + cropped store.  Replaces entropy_encoder.cpp:79-92,
+ * quantiser.cpp:72-85, discrete_cosine_transform.cpp:8-11,21-27,90-156,
+ * colour_mapping.cpp:69-92, block_grid.cpp:87-99. */
+int jea_idct_dequant(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, uint16_t width, uint16_t height,
+                     const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_rgb);
+
+/* Per-pixel colour maps on n interleaved triples (exhaustive-sweep test surface
+ * for colour_mapping.cpp:44-67 and :69-92). */
+int jea_rgb_to_ycbcr(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc);
+int jea_ycbcr_to_rgb(jea_ctx* ctx, const uint8_t* d_ycc, size_t n_pixels, uint8_t* d_rgb);
+
+/* ---- device memory helpers for callers without a HIP binding ---------- */
+int jea_malloc(jea_ctx* ctx, size_t bytes, void** d_ptr);
+int jea_free(jea_ctx* ctx, void* d_ptr);
+int jea_memcpy_h2d(jea_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int jea_memcpy_d2h(jea_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGENC_AMD_H_ */

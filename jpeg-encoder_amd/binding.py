@@ -1,0 +1,253 @@
+"""ctypes binding of include/jpegenc_amd.h."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjpegenc_amd.so")
+HEADER_BYTES = 607
+
+ERR_NAMES = {1: "INVALID_ARG", 2: "HIP", 3: "CAPACITY", 4: "RANGE", 5: "BAD_HEADER", 6: "BAD_STREAM",
+             7: "NO_EOI", 8: "NO_DEVICE"}
+
+EXPORTS = [
+    "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_get_stream", "jea_synchronize",
+    "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header",
+    "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
+    "jea_decode_batch", "jea_decode_host",
+    "jea_fdct_quant", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
+    "jea_rgb_to_ycbcr", "jea_ycbcr_to_rgb",
+    "jea_malloc", "jea_free", "jea_memcpy_h2d", "jea_memcpy_d2h",
+]
+
+
+class JeaError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%s)" % (message, ERR_NAMES.get(code, code)))
+        self.code = code
+        self.message = message
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library; raises if it is missing -- there is no other implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `make -C jpeg-encoder_amd/csrc`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, sz, u16, i32 = c.c_void_p, c.c_size_t, c.c_uint16, c.c_int
+    lib.jea_create.argtypes = [i32, c.POINTER(vp)]
+    lib.jea_destroy.argtypes = [vp]
+    lib.jea_destroy.restype = None
+    lib.jea_last_error.argtypes = [vp]
+    lib.jea_last_error.restype = c.c_char_p
+    lib.jea_set_stream.argtypes = [vp, vp]
+    lib.jea_get_stream.argtypes = [vp]
+    lib.jea_get_stream.restype = vp
+    lib.jea_synchronize.argtypes = [vp]
+    lib.jea_quant_tables.argtypes = [i32, vp, vp]
+    lib.jea_quant_tables.restype = None
+    lib.jea_write_header.argtypes = [vp, u16, u16, vp, vp]
+    lib.jea_write_header.restype = None
+    lib.jea_max_jpeg_bytes.argtypes = [u16, u16]
+    lib.jea_max_jpeg_bytes.restype = sz
+    lib.jea_check_header.argtypes = [vp, sz, c.POINTER(u16), c.POINTER(u16), c.POINTER(c.c_char_p)]
+    lib.jea_encode_batch.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp]
+    lib.jea_encode_batch_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
+    lib.jea_encode_host.argtypes = [vp, vp, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
+    lib.jea_decode_batch.argtypes = [vp, vp, vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_decode_host.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_fdct_quant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_block_bit_lengths.argtypes = [vp, vp, sz, sz, vp]
+    lib.jea_entropy_encode.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp]
+    lib.jea_entropy_decode.argtypes = [vp, vp, vp, vp, sz, sz, vp]
+    lib.jea_idct_dequant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_rgb_to_ycbcr.argtypes = [vp, vp, sz, vp]
+    lib.jea_ycbcr_to_rgb.argtypes = [vp, vp, sz, vp]
+    lib.jea_malloc.argtypes = [vp, sz, c.POINTER(vp)]
+    lib.jea_free.argtypes = [vp, vp]
+    lib.jea_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    lib.jea_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    _lib = lib
+    return lib
+
+
+def quant_tables(quality):
+    """Host-side helper (no GPU): Quantiser::Quantiser(quality) tables, natural order."""
+    lib = load_library()
+    lum, chrom = np.zeros(64, np.uint16), np.zeros(64, np.uint16)
+    lib.jea_quant_tables(int(quality), lum.ctypes.data, chrom.ctypes.data)
+    return lum, chrom
+
+
+def write_header(w, h, lum, chrom):
+    lib = load_library()
+    out = np.zeros(HEADER_BYTES, np.uint8)
+    lib.jea_write_header(out.ctypes.data, w, h, lum.ctypes.data, chrom.ctypes.data)
+    return out.tobytes()
+
+
+def max_jpeg_bytes(w, h):
+    return load_library().jea_max_jpeg_bytes(w, h)
+
+
+def check_header(jpeg):
+    """Returns (ok, message, hdr_w, hdr_h)."""
+    lib = load_library()
+    buf = np.frombuffer(jpeg, np.uint8)
+    w, h, msg = ctypes.c_uint16(0), ctypes.c_uint16(0), ctypes.c_char_p()
+    rc = lib.jea_check_header(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(msg))
+    return rc == 0, (msg.value.decode() if msg.value else None), w.value, h.value
+
+
+def n_mcu(w, h):
+    return ((w + 7) // 8) * ((h + 7) // 8)
+
+
+class Context:
+    """One jea_ctx on one GPU.  Device buffers are torch tensors on that GPU."""
+
+    def __init__(self, device=0):
+        import torch  # device memory only
+
+        self.torch = torch
+        self.lib = load_library()
+        self.device = device
+        self.handle = ctypes.c_void_p()
+        rc = self.lib.jea_create(device, ctypes.byref(self.handle))
+        if rc:
+            raise JeaError(rc, self.lib.jea_last_error(None).decode())
+        self.tdev = torch.device("cuda", device)
+
+    def close(self):
+        if self.handle:
+            self.lib.jea_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise JeaError(rc, self.lib.jea_last_error(self.handle).decode())
+
+    def synchronize(self):
+        self._check(self.lib.jea_synchronize(self.handle))
+
+    @property
+    def stream_handle(self):
+        return self.lib.jea_get_stream(self.handle)
+
+    def to_device(self, array):
+        t = self.torch.from_numpy(np.ascontiguousarray(array)).to(self.tdev)
+        self.torch.cuda.synchronize(self.tdev)
+        return t
+
+    def empty(self, n, dtype):
+        return self.torch.empty(int(n), dtype=dtype, device=self.tdev)
+
+    # ---- stages ----
+    def fdct_quant(self, d_rgb, n_images, w, h, lum, chrom):
+        coefs = self.empty(n_images * n_mcu(w, h) * 192, self.torch.int16)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_fdct_quant(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
+                                            chrom.ctypes.data, coefs.data_ptr()))
+        return coefs
+
+    def idct_dequant(self, d_coefs, n_images, w, h, lum, chrom):
+        rgb = self.empty(n_images * 3 * w * h, self.torch.uint8)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_idct_dequant(self.handle, d_coefs.data_ptr(), n_images, w, h, lum.ctypes.data,
+                                              chrom.ctypes.data, rgb.data_ptr()))
+        return rgb
+
+    def block_bit_lengths(self, d_coefs, n_images, mcus):
+        out = self.empty(n_images * mcus * 3, self.torch.int16)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_block_bit_lengths(self.handle, d_coefs.data_ptr(), n_images, mcus, out.data_ptr()))
+        return out
+
+    def entropy_encode(self, d_coefs, n_images, mcus, capacity):
+        out = self.empty(capacity, self.torch.uint8)
+        offsets, sizes = np.zeros(n_images, np.uint64), np.zeros(n_images, np.uint64)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_entropy_encode(self.handle, d_coefs.data_ptr(), n_images, mcus, out.data_ptr(),
+                                                capacity, offsets.ctypes.data, sizes.ctypes.data))
+        return out, offsets, sizes
+
+    def entropy_decode(self, d_scan, offsets, sizes, mcus):
+        n = len(offsets)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        sizes = np.ascontiguousarray(sizes, np.uint64)
+        coefs = self.empty(n * mcus * 192, self.torch.int16)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_entropy_decode(self.handle, d_scan.data_ptr(), offsets.ctypes.data,
+                                                sizes.ctypes.data, n, mcus, coefs.data_ptr()))
+        return coefs
+
+    def rgb_to_ycbcr(self, d_rgb):
+        out = self.torch.empty_like(d_rgb)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_rgb_to_ycbcr(self.handle, d_rgb.data_ptr(), d_rgb.numel() // 3, out.data_ptr()))
+        return out
+
+    def ycbcr_to_rgb(self, d_ycc):
+        out = self.torch.empty_like(d_ycc)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_ycbcr_to_rgb(self.handle, d_ycc.data_ptr(), d_ycc.numel() // 3, out.data_ptr()))
+        return out
+
+    # ---- whole path ----
+    def encode_batch(self, d_rgb, n_images, w, h, lum, chrom, capacity=None, d_out=None):
+        if capacity is None:
+            capacity = n_images * max_jpeg_bytes(w, h)
+        if d_out is None:
+            d_out = self.empty(capacity, self.torch.uint8)
+        offsets, sizes = np.zeros(n_images, np.uint64), np.zeros(n_images, np.uint64)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_encode_batch(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
+                                              chrom.ctypes.data, d_out.data_ptr(), capacity, offsets.ctypes.data,
+                                              sizes.ctypes.data))
+        return d_out, offsets, sizes
+
+    def encode_batch_async(self, d_rgb, n_images, w, h, lum, chrom, d_out, d_offsets, d_sizes, d_status):
+        self._check(self.lib.jea_encode_batch_async(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
+                                                    chrom.ctypes.data, d_out.data_ptr(), d_out.numel(),
+                                                    d_offsets.data_ptr(), d_sizes.data_ptr(), d_status.data_ptr()))
+
+    def encode_host(self, rgb, lum, chrom, capacity=None):
+        h, w = rgb.shape[:2]
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        if capacity is None:
+            capacity = max_jpeg_bytes(w, h)
+        out = np.zeros(capacity, np.uint8)
+        n = ctypes.c_size_t(0)
+        self._check(self.lib.jea_encode_host(self.handle, rgb.ctypes.data, w, h, lum.ctypes.data, chrom.ctypes.data,
+                                             out.ctypes.data, capacity, ctypes.byref(n)))
+        return out[: n.value].tobytes()
+
+    def decode_batch(self, d_jpeg, offsets, sizes, w, h, lum, chrom):
+        n = len(offsets)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        sizes = np.ascontiguousarray(sizes, np.uint64)
+        rgb = self.empty(n * 3 * w * h, self.torch.uint8)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_decode_batch(self.handle, d_jpeg.data_ptr(), offsets.ctypes.data, sizes.ctypes.data,
+                                              n, w, h, lum.ctypes.data, chrom.ctypes.data, rgb.data_ptr()))
+        return rgb
+
+    def decode_host(self, jpeg, w, h, lum, chrom):
+        buf = np.frombuffer(jpeg, np.uint8)
+        rgb = np.zeros((h, w, 3), np.uint8)
+        self._check(self.lib.jea_decode_host(self.handle, buf.ctypes.data, buf.size, w, h, lum.ctypes.data,
+                                             chrom.ctypes.data, rgb.ctypes.data))
+        return rgb

@@ -1,0 +1,670 @@
+// C-ABI of the library (include/jpegenc_amd.h): argument checks, scratch
+// management and the order in which the kernels are enqueued.  All arithmetic on
+// image data happens in the kernels (fdct.hip, entropy.hip); the only host-side
+// computation is table and header construction, which the reference also does
+// once per encoder object / per file on the host
+// (jpeg/src/quantiser.cpp:3-55, jpeg/src/encoder.cpp:74-138,140-283).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/jpegenc_amd.h"
+#include "kernels.h"
+#include "tables.h"
+
+using namespace jea;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct jea_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+    HuffTables* d_huff = nullptr;
+    DecodeTables* d_decode = nullptr;
+    int32_t* d_status = nullptr;
+    // scratch, grown on demand and kept
+    DeviceBuffer coefs, len16, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
+    DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
+};
+
+namespace {
+
+int fail(jea_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg; else g_create_error = msg;
+    return code;
+}
+
+#define JEA_HIP(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, JEA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+int ensure(jea_ctx* ctx, DeviceBuffer& b, size_t bytes) {
+    if (bytes <= b.bytes) return JEA_OK;
+    // work that still uses the old allocation must drain before it is freed
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.ptr) JEA_HIP(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    JEA_HIP(ctx, hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return JEA_OK;
+}
+
+void free_buffer(DeviceBuffer& b) {
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+}
+
+// Canonical code assignment (T.81 Annex C) from the DHT-form tables.
+void build_codes(const uint8_t bits[16], const uint8_t* vals, uint32_t* out /* indexed by symbol */, int n_out) {
+    for (int i = 0; i < n_out; ++i) out[i] = 0;
+    uint32_t code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        for (int i = 0; i < bits[l - 1]; ++i, ++k) out[vals[k]] = ((uint32_t)l << 16) | code++;
+        code <<= 1;
+    }
+}
+
+void build_decode_table(const uint8_t bits[16], const uint8_t* vals, DecodeTable& t) {
+    std::memset(&t, 0, sizeof(t));
+    uint32_t code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t.maxcode[l] = -1;
+        t.valoff[l] = k - (int)code;
+        for (int i = 0; i < bits[l - 1]; ++i, ++k) {
+            t.vals[k] = vals[k];
+            if (l <= 9) {
+                const uint32_t first = code << (9 - l);
+                for (uint32_t j = 0; j < (1u << (9 - l)); ++j) t.fast[first + j] = (uint16_t)((l << 8) | vals[k]);
+            }
+            t.maxcode[l] = (int32_t)code;
+            ++code;
+        }
+        code <<= 1;
+    }
+    t.maxcode[0] = -1;
+    t.maxcode[17] = -1;
+}
+
+bool valid_dims(uint16_t w, uint16_t h) { return w >= 1 && h >= 1; }
+
+size_t mcus_of(uint16_t w, uint16_t h) { return (size_t)((w + 7) / 8) * (size_t)((h + 7) / 8); }
+
+QuantTables to_float_tables(const uint16_t lum_q[64], const uint16_t chr_q[64]) {
+    QuantTables q;
+    for (int i = 0; i < 64; ++i) {
+        q.lum[i] = (float)lum_q[i];
+        q.chr[i] = (float)chr_q[i];
+    }
+    return q;
+}
+
+bool tables_ok(const uint16_t lum_q[64], const uint16_t chr_q[64]) {
+    if (!lum_q || !chr_q) return false;
+    for (int i = 0; i < 64; ++i)
+        if (lum_q[i] == 0 || chr_q[i] == 0) return false;
+    return true;
+}
+
+// Scratch of one entropy-encode pass.
+int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t out_capacity, EntropyScratch& sc) {
+    const size_t nbc = mcus * 3, n_tiles = tiles_per_image(mcus);
+    int rc;
+    if ((rc = ensure(ctx, ctx->len16, n_images * nbc * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->tile_bits, n_images * n_tiles * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->tile_base, n_images * n_tiles * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->tile_ff, n_images * n_tiles * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->tile_ffbase, n_images * n_tiles * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->img_words, 3 * n_images * sizeof(uint64_t)))) return rc;
+    // The packed stream of an image is never longer than its stuffed one.
+    const size_t worst = n_images * ((nbc * 1660 + 7) / 8 + 16);
+    const size_t ucap = (out_capacity + 16 * n_images < worst) ? out_capacity + 16 * n_images : worst;
+    if ((rc = ensure(ctx, ctx->unstuffed, ucap))) return rc;
+    sc.len16 = (uint16_t*)ctx->len16.ptr;
+    sc.tile_bits = (uint32_t*)ctx->tile_bits.ptr;
+    sc.tile_base = (uint64_t*)ctx->tile_base.ptr;
+    sc.tile_ff = (uint32_t*)ctx->tile_ff.ptr;
+    sc.tile_ffbase = (uint64_t*)ctx->tile_ffbase.ptr;
+    sc.img_bits = (uint64_t*)ctx->img_words.ptr;
+    sc.img_ubase = sc.img_bits + n_images;
+    sc.img_ff = sc.img_ubase + n_images;
+    sc.unstuffed = (uint8_t*)ctx->unstuffed.ptr;
+    sc.unstuffed_capacity = ucap;
+    return JEA_OK;
+}
+
+int finish_status(jea_ctx* ctx, const int32_t* d_status, const char* what) {
+    int32_t st = 0;
+    JEA_HIP(ctx, hipMemcpyAsync(&st, d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    switch (st) {
+        case JEA_OK: return JEA_OK;
+        case JEA_ERR_CAPACITY: return fail(ctx, st, std::string(what) + ": output capacity too small");
+        case JEA_ERR_RANGE: return fail(ctx, st, "Invalid runtime encoding encountered.");  // entropy_encoder.cpp:748
+        case JEA_ERR_BAD_STREAM: return fail(ctx, st, "Invalid Huffman code encountered in input JPEG data.");
+        case JEA_ERR_NO_EOI: return fail(ctx, st, "Failed to find EOI marker");
+        default: return fail(ctx, st, std::string(what) + ": device reported status " + std::to_string(st));
+    }
+}
+
+struct HeaderCheck {
+    const uint8_t* d;
+    size_t p = 0;
+    unsigned u8() { return d[p++]; }
+    unsigned u16() { p += 2; return (unsigned)((d[p - 2] << 8) | d[p - 1]); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int jea_create(int device_id, jea_ctx** out_ctx) {
+    if (!out_ctx) return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, JEA_ERR_NO_DEVICE, "jea_create: no HIP device available");
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: device_id out of range");
+    jea_ctx* ctx = new (std::nothrow) jea_ctx();
+    if (!ctx) return fail(nullptr, JEA_ERR_HIP, "jea_create: out of host memory");
+    ctx->device = device_id;
+    auto bail = [&](const char* what, hipError_t e) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        jea_destroy(ctx);
+        return fail(nullptr, JEA_ERR_HIP, msg);
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    ctx->stream = ctx->own_stream;
+
+    HuffTables ht;
+    build_codes(kDcLumBits, kDcVals, ht.dc[0], 12);
+    build_codes(kDcChrBits, kDcVals, ht.dc[1], 12);
+    build_codes(kAcLumBits, kAcLumVals, ht.ac[0], 256);
+    build_codes(kAcChrBits, kAcChrVals, ht.ac[1], 256);
+    DecodeTables dt;
+    build_decode_table(kDcLumBits, kDcVals, dt.tab[0]);
+    build_decode_table(kAcLumBits, kAcLumVals, dt.tab[1]);
+    build_decode_table(kDcChrBits, kDcVals, dt.tab[2]);
+    build_decode_table(kAcChrBits, kAcChrVals, dt.tab[3]);
+    if ((e = hipMalloc((void**)&ctx->d_huff, sizeof(HuffTables))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&ctx->d_decode, sizeof(DecodeTables))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&ctx->d_status, 64)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(ctx->d_huff, &ht, sizeof(ht), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    if ((e = hipMemcpy(ctx->d_decode, &dt, sizeof(dt), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail("hipMemcpy", e);
+    *out_ctx = ctx;
+    return JEA_OK;
+}
+
+void jea_destroy(jea_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (DeviceBuffer* b : {&ctx->coefs, &ctx->len16, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
+                            &ctx->tile_ffbase, &ctx->img_words, &ctx->unstuffed, &ctx->stage_in, &ctx->stage_out,
+                            &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes})
+        free_buffer(*b);
+    if (ctx->d_huff) (void)hipFree(ctx->d_huff);
+    if (ctx->d_decode) (void)hipFree(ctx->d_decode);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* jea_last_error(const jea_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int jea_set_stream(jea_ctx* ctx, void* hip_stream) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return JEA_OK;
+}
+
+void* jea_get_stream(jea_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int jea_synchronize(jea_ctx* ctx) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+// ---- tables ---------------------------------------------------------------
+
+void jea_quant_tables(int quality, uint16_t lum_q[64], uint16_t chr_q[64]) {
+    if (quality < 1) quality = 1;  // quantiser.cpp:6-11
+    else if (quality > 100) quality = 100;
+    // :25 -- the scale is formed in integer arithmetic, then held in a float
+    const float S = (float)((quality < 50) ? 5000 / quality : 200 - 2 * quality);
+    for (int i = 0; i < 64; ++i) {
+        // :27-29 / :48-50 -- float arithmetic, floor, narrowing to uint16; :30-32 zero becomes one
+        lum_q[i] = (uint16_t)std::floor((S * (float)kBaseLum[i] + 50.0f) / 100.0f);
+        chr_q[i] = (uint16_t)std::floor((S * (float)kBaseChr[i] + 50.0f) / 100.0f);
+        if (lum_q[i] == 0) lum_q[i] = 1;
+        if (chr_q[i] == 0) chr_q[i] = 1;
+    }
+}
+
+void jea_write_header(uint8_t out[JEA_HEADER_BYTES], uint16_t width, uint16_t height, const uint16_t lum_q[64],
+                      const uint16_t chr_q[64]) {
+    size_t p = 0;
+    auto b = [&](unsigned v) { out[p++] = (uint8_t)v; };
+    auto w = [&](unsigned v) { out[p++] = (uint8_t)(v >> 8); out[p++] = (uint8_t)v; };
+    w(0xFFD8);                                                  // SOI, encoder.cpp:76
+    w(0xFFE0); w(16);                                           // APP0 :79-90
+    b('J'); b('F'); b('I'); b('F'); b(0);
+    w(0x0102); b(0); w(0x0010); w(0x0010); w(0x0000);
+    w(0xFFDB); w(2 + 2 * 65);                                   // DQT, quantiser.cpp:87-102
+    b(0x00);
+    for (int k = 0; k < 64; ++k) b(lum_q[kZigzag[k]]);          // pushByte keeps the low 8 bits
+    b(0x01);
+    for (int k = 0; k < 64; ++k) b(chr_q[kZigzag[k]]);
+    w(0xFFC0); w(17); b(8); w(height); w(width); b(3);          // SOF0, encoder.cpp:99-116
+    b(1); b(0x11); b(0);
+    b(2); b(0x11); b(1);
+    b(3); b(0x11); b(1);
+    w(0xFFC4); w(2 + 4 * 17 + 12 + 12 + 162 + 162);             // DHT, entropy_encoder.cpp:672-693
+    b(0x00); for (int i = 0; i < 16; ++i) b(kDcLumBits[i]); for (int i = 0; i < 12; ++i) b(kDcVals[i]);
+    b(0x10); for (int i = 0; i < 16; ++i) b(kAcLumBits[i]); for (int i = 0; i < 162; ++i) b(kAcLumVals[i]);
+    b(0x01); for (int i = 0; i < 16; ++i) b(kDcChrBits[i]); for (int i = 0; i < 12; ++i) b(kDcVals[i]);
+    b(0x11); for (int i = 0; i < 16; ++i) b(kAcChrBits[i]); for (int i = 0; i < 162; ++i) b(kAcChrVals[i]);
+    w(0xFFDA); w(12); b(3);                                     // SOS, encoder.cpp:122-137
+    b(1); b(0x00); b(2); b(0x11); b(3); b(0x11);
+    w(0x003F); b(0x00);
+}
+
+size_t jea_max_jpeg_bytes(uint16_t width, uint16_t height) {
+    // 1660 bits per block-channel at most (22-bit DC + 63 x 26-bit AC); stuffing can double it
+    return JEA_HEADER_BYTES + 2 * ((mcus_of(width, height) * 3 * 1660 + 7) / 8) + 3;
+}
+
+int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uint16_t* hdr_height,
+                     const char** msg) {
+    const char* m = nullptr;
+    uint16_t hw = 0, hh = 0;
+    // Field order and messages: encoder.cpp:141-281.
+    if (!h_jpeg || len < JEA_HEADER_BYTES) {
+        m = "Failed to find SOI marker";
+    } else {
+        HeaderCheck r{h_jpeg};
+#define NEED(cond, text) if (!m && !(cond)) m = text
+        NEED(r.u16() == 0xFFD8, "Failed to find SOI marker");
+        NEED(r.u16() == 0xFFE0, "Failed to find APP-0 marker");
+        {
+            const size_t start = r.p;
+            const unsigned l = r.u16();
+            NEED(r.u8() == 'J', "Failed to find 'J'(FIF) in APP-0 payload");
+            NEED(r.u8() == 'F', "Failed to find (J)'F'(IF) in APP-0 payload");
+            NEED(r.u8() == 'I', "Failed to find (JF)'I'(F) in APP-0 payload");
+            NEED(r.u8() == 'F', "Failed to find (JFI)'F' in APP-0 payload");
+            NEED(r.u8() == 0, "Failed to find 'JFIF' null-terminator in APP-0 payload");
+            NEED(r.u16() == 0x0102, "JFIF version indicated by APP-0 payload is not 1.02");
+            NEED(r.u8() == 0, "Failed to find density units in APP-0 payload");
+            NEED(r.u16() == 0x0010, "Failed to find Xdensity in APP-0 payload");
+            NEED(r.u16() == 0x0010, "Failed to find Ydensity in APP-0 payload");
+            NEED(r.u16() == 0x0000, "Failed to find thumbnail size in APP-0 payload");
+            NEED(l == r.p - start, "APP-0 length parameter does not correspond to payload size");
+        }
+        r.p += 2 + 2 + 2 * 65;  // DQT skipped, :188
+        NEED(r.u16() == 0xFFC0, "Failed to find SOF0 marker");
+        {
+            const size_t start = r.p;
+            const unsigned l = r.u16();
+            NEED(r.u8() == 8, "Failed to find precision in SOF0 payload");
+            hh = (uint16_t)r.u16();
+            hw = (uint16_t)r.u16();
+            NEED(r.u8() == 3, "Failed to find number of components in SOF0 payload");
+            NEED(r.u8() == 1, "Failed to find first component ID in SOF0 payload");
+            NEED(r.u8() == 0x11, "Failed to find first component sampling factors in SOF0 payload");
+            NEED(r.u8() == 0, "Failed to find first component quantisation table ID in SOF0 payload");
+            NEED(r.u8() == 2, "Failed to find second component ID in SOF0 payload");
+            NEED(r.u8() == 0x11, "Failed to find second component sampling factors in SOF0 payload");
+            NEED(r.u8() == 1, "Failed to find second component quantisation table ID in SOF0 payload");
+            NEED(r.u8() == 3, "Failed to find third component ID in SOF0 payload");
+            NEED(r.u8() == 0x11, "Failed to find third component sampling factors in SOF0 payload");
+            NEED(r.u8() == 1, "Failed to find third component quantisation table ID in SOF0 payload");
+            NEED(l == r.p - start, "SOF0 length parameter does not correspond to payload size");
+        }
+        r.p += 2 + 2 + 4 + 412;  // DHT skipped, :240
+        NEED(r.u16() == 0xFFDA, "Failed to find SOS marker");
+        {
+            const size_t start = r.p;
+            const unsigned l = r.u16();
+            NEED(r.u8() == 3, "Failed to find number of components in SOS payload");
+            NEED(r.u8() == 1, "Failed to find first component ID in SOS payload");
+            NEED(r.u8() == 0x00, "Failed to find first component Huffman table ID in SOS payload");
+            NEED(r.u8() == 2, "Failed to find second component ID in SOS payload");
+            NEED(r.u8() == 0x11, "Failed to find second component Huffman table ID in SOS payload");
+            NEED(r.u8() == 3, "Failed to find third component ID in SOS payload");
+            NEED(r.u8() == 0x11, "Failed to find third component Huffman table ID in SOS payload");
+            NEED(r.u16() == 0x003F, "Failed to find spectral alignment in SOS payload");
+            NEED(r.u8() == 0, "Failed to find skip byte in SOS payload");
+            NEED(l == r.p - start, "SOS length parameter does not correspond to payload size");
+        }
+#undef NEED
+    }
+    if (hdr_width) *hdr_width = hw;
+    if (hdr_height) *hdr_height = hh;
+    if (msg) *msg = m;
+    return m ? JEA_ERR_BAD_HEADER : JEA_OK;
+}
+
+// ---- stage entry points -----------------------------------------------------
+
+int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                   const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb || !d_coefs || n_images == 0 || n_images > 65535 || !valid_dims(width, height) ||
+        !tables_ok(lum_q, chr_q))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_fdct_quant: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+int jea_idct_dequant(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, uint16_t width, uint16_t height,
+                     const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_rgb) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb || !d_coefs || n_images == 0 || n_images > 65535 || !valid_dims(width, height) ||
+        !tables_ok(lum_q, chr_q))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_idct_dequant: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    launch_idct_dequant(ctx->stream, d_coefs, n_images, width, height, to_float_tables(lum_q, chr_q), d_rgb);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+int jea_rgb_to_ycbcr(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb || !d_ycc || n_pixels == 0) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_rgb_to_ycbcr: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    launch_rgb_to_ycbcr(ctx->stream, d_rgb, n_pixels, d_ycc);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+int jea_ycbcr_to_rgb(jea_ctx* ctx, const uint8_t* d_ycc, size_t n_pixels, uint8_t* d_rgb) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb || !d_ycc || n_pixels == 0) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_ycbcr_to_rgb: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    launch_ycbcr_to_rgb(ctx->stream, d_ycc, n_pixels, d_rgb);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+int jea_block_bit_lengths(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
+                          uint16_t* d_lengths) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_coefs || !d_lengths || n_images == 0 || n_images > 65535 || mcus_per_image == 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_block_bit_lengths: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->tile_bits, n_images * tiles_per_image(mcus_per_image) * sizeof(uint32_t)))) return rc;
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    launch_bit_lengths(ctx->stream, d_coefs, n_images, mcus_per_image, ctx->d_huff, d_lengths,
+                       (uint32_t*)ctx->tile_bits.ptr, ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    return finish_status(ctx, ctx->d_status, "jea_block_bit_lengths");
+}
+
+static int entropy_encode_common(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus,
+                                 const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
+                                 size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
+    EntropyScratch sc;
+    int rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc);
+    if (rc) return rc;
+    JEA_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t), ctx->stream));
+    launch_entropy_encode(ctx->stream, d_coefs, n_images, mcus, ctx->d_huff, sc, header, header_len, with_eoi, d_out,
+                          out_capacity, d_offsets, d_sizes, d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    return JEA_OK;
+}
+
+static int fetch_offsets_sizes(jea_ctx* ctx, size_t n_images, const uint64_t* d_offsets, const uint64_t* d_sizes,
+                               uint64_t* h_offsets, uint64_t* h_sizes) {
+    JEA_HIP(ctx, hipMemcpyAsync(h_offsets, d_offsets, n_images * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipMemcpyAsync(h_sizes, d_sizes, n_images * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    return JEA_OK;
+}
+
+int jea_entropy_encode(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image, uint8_t* d_out,
+                       size_t out_capacity, uint64_t* h_offsets, uint64_t* h_sizes) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_coefs || !d_out || !h_offsets || !h_sizes || n_images == 0 || n_images > 65535 || mcus_per_image == 0 ||
+        out_capacity == 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_entropy_encode: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->out_offsets, n_images * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->out_sizes, n_images * sizeof(uint64_t)))) return rc;
+    HeaderBytes hb{};
+    rc = entropy_encode_common(ctx, d_coefs, n_images, mcus_per_image, hb, 0, false, d_out, out_capacity,
+                               (uint64_t*)ctx->out_offsets.ptr, (uint64_t*)ctx->out_sizes.ptr, ctx->d_status);
+    if (rc) return rc;
+    if ((rc = fetch_offsets_sizes(ctx, n_images, (uint64_t*)ctx->out_offsets.ptr, (uint64_t*)ctx->out_sizes.ptr,
+                                  h_offsets, h_sizes)))
+        return rc;
+    return finish_status(ctx, ctx->d_status, "jea_entropy_encode");
+}
+
+// ---- whole encode -------------------------------------------------------------
+
+int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                           const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
+                           uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb || !d_out || !d_offsets || !d_sizes || !d_status || n_images == 0 || n_images > 65535 ||
+        !valid_dims(width, height) || !tables_ok(lum_q, chr_q) || out_capacity < JEA_HEADER_BYTES + 3)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mcus = mcus_of(width, height);
+    int rc;
+    if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
+    HeaderBytes hb{};
+    jea_write_header(hb.b, width, height, lum_q, chr_q);
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs);
+    JEA_HIP(ctx, hipGetLastError());
+    return entropy_encode_common(ctx, d_coefs, n_images, mcus, hb, JEA_HEADER_BYTES, true, d_out, out_capacity,
+                                 d_offsets, d_sizes, d_status);
+}
+
+int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                     const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
+                     uint64_t* h_offsets, uint64_t* h_sizes) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_offsets || !h_sizes || n_images == 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch: invalid argument");
+    int rc;
+    if ((rc = ensure(ctx, ctx->out_offsets, n_images * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->out_sizes, n_images * sizeof(uint64_t)))) return rc;
+    uint64_t* d_offsets = (uint64_t*)ctx->out_offsets.ptr;
+    uint64_t* d_sizes = (uint64_t*)ctx->out_sizes.ptr;
+    rc = jea_encode_batch_async(ctx, d_rgb, n_images, width, height, lum_q, chr_q, d_out, out_capacity, d_offsets,
+                                d_sizes, ctx->d_status);
+    if (rc) return rc;
+    if ((rc = fetch_offsets_sizes(ctx, n_images, d_offsets, d_sizes, h_offsets, h_sizes))) return rc;
+    return finish_status(ctx, ctx->d_status, "jea_encode_batch");
+}
+
+int jea_encode_host(jea_ctx* ctx, const uint8_t* h_rgb, uint16_t width, uint16_t height, const uint16_t lum_q[64],
+                    const uint16_t chr_q[64], uint8_t* h_out, size_t out_capacity, size_t* out_len) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_rgb || !h_out || !out_len || !valid_dims(width, height) || out_capacity < JEA_HEADER_BYTES + 3)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_host: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = (size_t)3 * width * height;
+    const size_t worst = jea_max_jpeg_bytes(width, height);
+    const size_t cap = out_capacity < worst ? out_capacity : worst;
+    int rc;
+    if ((rc = ensure(ctx, ctx->stage_in, in_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, cap))) return rc;
+    JEA_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, h_rgb, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t off = 0, size = 0;
+    rc = jea_encode_batch(ctx, (const uint8_t*)ctx->stage_in.ptr, 1, width, height, lum_q, chr_q,
+                          (uint8_t*)ctx->stage_out.ptr, cap, &off, &size);
+    if (rc) return rc;
+    JEA_HIP(ctx, hipMemcpyAsync(h_out, (const uint8_t*)ctx->stage_out.ptr + off, size, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_len = (size_t)size;
+    return JEA_OK;
+}
+
+// ---- decode -------------------------------------------------------------------
+
+static int upload_segments(jea_ctx* ctx, const uint64_t* h_offsets, const uint64_t* h_sizes, size_t n_images,
+                           uint64_t skip) {
+    int rc;
+    if ((rc = ensure(ctx, ctx->seg_offsets, n_images * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->seg_sizes, n_images * sizeof(uint64_t)))) return rc;
+    std::vector<uint64_t> off(n_images), sz(n_images);
+    for (size_t i = 0; i < n_images; ++i) {
+        if (h_sizes[i] < skip + 2) return fail(ctx, JEA_ERR_NO_EOI, "Failed to find EOI marker");
+        off[i] = h_offsets[i] + skip;
+        sz[i] = h_sizes[i] - skip;
+    }
+    // the vectors die at return: use the blocking copy
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JEA_HIP(ctx, hipMemcpy(ctx->seg_offsets.ptr, off.data(), n_images * sizeof(uint64_t), hipMemcpyHostToDevice));
+    JEA_HIP(ctx, hipMemcpy(ctx->seg_sizes.ptr, sz.data(), n_images * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return JEA_OK;
+}
+
+int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_offsets, const uint64_t* h_sizes,
+                       size_t n_images, size_t mcus_per_image, int16_t* d_coefs) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_scan || !h_offsets || !h_sizes || !d_coefs || n_images == 0 || mcus_per_image == 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_entropy_decode: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = upload_segments(ctx, h_offsets, h_sizes, n_images, 0);
+    if (rc) return rc;
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    launch_entropy_decode(ctx->stream, d_scan, (const uint64_t*)ctx->seg_offsets.ptr,
+                          (const uint64_t*)ctx->seg_sizes.ptr, n_images, mcus_per_image, ctx->d_decode, d_coefs,
+                          ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    return finish_status(ctx, ctx->d_status, "jea_entropy_decode");
+}
+
+int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offsets, const uint64_t* h_sizes,
+                     size_t n_images, uint16_t width, uint16_t height, const uint16_t lum_q[64],
+                     const uint16_t chr_q[64], uint8_t* d_rgb) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_jpeg || !h_offsets || !h_sizes || !d_rgb || n_images == 0 || n_images > 65535 ||
+        !valid_dims(width, height) || !tables_ok(lum_q, chr_q))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_decode_batch: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    // Header validation on the host, as the reference does before touching scan data (encoder.cpp:48).
+    std::vector<uint8_t> hdr(JEA_HEADER_BYTES);
+    for (size_t i = 0; i < n_images; ++i) {
+        if (h_sizes[i] < JEA_HEADER_BYTES) return fail(ctx, JEA_ERR_BAD_HEADER, "Failed to find SOI marker");
+        JEA_HIP(ctx, hipMemcpyAsync(hdr.data(), d_jpeg + h_offsets[i], JEA_HEADER_BYTES, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const char* msg = nullptr;
+        if (jea_check_header(hdr.data(), JEA_HEADER_BYTES, nullptr, nullptr, &msg) != JEA_OK)
+            return fail(ctx, JEA_ERR_BAD_HEADER, msg);
+    }
+    const size_t mcus = mcus_of(width, height);
+    int rc;
+    if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    if ((rc = upload_segments(ctx, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES))) return rc;
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    launch_entropy_decode(ctx->stream, d_jpeg, (const uint64_t*)ctx->seg_offsets.ptr,
+                          (const uint64_t*)ctx->seg_sizes.ptr, n_images, mcus, ctx->d_decode,
+                          (int16_t*)ctx->coefs.ptr, ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    // As in the reference, nothing is written to the output when the stream is bad (encoder.cpp:63-70).
+    if ((rc = finish_status(ctx, ctx->d_status, "jea_decode_batch"))) return rc;
+    launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height,
+                        to_float_tables(lum_q, chr_q), d_rgb);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t width, uint16_t height,
+                    const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* h_rgb) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_jpeg || !h_rgb || !valid_dims(width, height))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_decode_host: invalid argument");
+    const char* msg = nullptr;
+    if (jea_check_header(h_jpeg, len, nullptr, nullptr, &msg) != JEA_OK) return fail(ctx, JEA_ERR_BAD_HEADER, msg);
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t out_bytes = (size_t)3 * width * height;
+    int rc;
+    if ((rc = ensure(ctx, ctx->stage_out, len))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_in, out_bytes))) return rc;
+    JEA_HIP(ctx, hipMemcpyAsync(ctx->stage_out.ptr, h_jpeg, len, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t off = 0, size = len;
+    rc = jea_decode_batch(ctx, (const uint8_t*)ctx->stage_out.ptr, &off, &size, 1, width, height, lum_q, chr_q,
+                          (uint8_t*)ctx->stage_in.ptr);
+    if (rc) return rc;
+    JEA_HIP(ctx, hipMemcpyAsync(h_rgb, ctx->stage_in.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+// ---- device memory helpers ---------------------------------------------------
+
+int jea_malloc(jea_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr || bytes == 0) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    JEA_HIP(ctx, hipMalloc(d_ptr, bytes));
+    return JEA_OK;
+}
+int jea_free(jea_ctx* ctx, void* d_ptr) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JEA_HIP(ctx, hipFree(d_ptr));
+    return JEA_OK;
+}
+int jea_memcpy_h2d(jea_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || !d_dst || !h_src) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    JEA_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+int jea_memcpy_d2h(jea_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx || !h_dst || !d_src) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    JEA_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,670 @@
+// Parallel Huffman entropy coding for gfx950.
+//
+// The reference appends the bits of one block-channel after another to a single
+// serial BitStream (jpeg/src/encoder.cpp:21-27, jpeg/src/bit_stream.cpp:44-81),
+// then byte-stuffs the committed bytes (bit_stream.cpp:127-134, intended
+// semantics: a 0x00 after every 0xFF), zero-pads the last byte and appends EOI
+// (encoder.cpp:29-32).  Here the same byte string is produced in parallel:
+//
+//   bit_length_kernel   one thread per block-channel: run-length symbols and
+//                       total bit length (entropy_encoder.cpp:94-120, 715-765);
+//                       the DC difference needs only the previous MCU's DC of
+//                       the same channel, read straight from the coefficients
+//   scan_tiles_kernel   exclusive scan of the per-tile bit totals of each image
+//   pack_kernel         every tile regenerates its symbols, assembles them MSB
+//                       first in an LDS window at the scanned bit offset and
+//                       writes the bytes it owns of the not-yet-stuffed stream;
+//                       it also counts the 0xFF bytes among them
+//   scan_tiles_kernel   exclusive scan of the per-tile 0xFF counts
+//   stuff_kernel        copies each tile's bytes to their final place,
+//                       inserting 0x00 after 0xFF; writes header and EOI
+//
+// A tile is kTileBlocks = 252 consecutive block-channels (84 MCUs) of one image.
+// Byte ownership: a byte belongs to the tile that holds its first bit, so the
+// byte that straddles two tiles is produced by the earlier tile, which for that
+// purpose also encodes the first MCU of the next tile (3 block-channels are at
+// least 14 bits, more than the 7 that can be missing).  No atomics on global
+// memory and no zero-filled output are needed.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "tables.h"
+#include "../../include/jpegenc_amd.h"
+
+namespace jea {
+
+namespace {
+
+constexpr int kEntThreads = 256;
+constexpr uint32_t kWinWords = 4096;  // 16 KiB LDS window of the packed stream
+
+struct HuffLds {
+    uint32_t dc[2][12];
+    uint32_t ac[2][256];
+};
+
+__device__ __forceinline__ void load_huff(HuffLds& h, const HuffTables* __restrict__ g) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&h);
+    for (uint32_t i = threadIdx.x; i < sizeof(HuffLds) / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// The 64 zig-zag coefficients of one block-channel as loaded (8 x 16 bytes).
+struct BlockRegs {
+    uint32_t w[32];
+    __device__ __forceinline__ int at(int k) const { return (int)(int16_t)(w[k >> 1] >> (16 * (k & 1))); }
+};
+
+__device__ __forceinline__ void load_block(BlockRegs& r, const int16_t* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 v = q[i];
+        r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ uint32_t bit_width(uint32_t v) { return 32u - (uint32_t)__clz((int)v); }
+
+// Symbol generation for one block-channel, shared by the length pass and the
+// pack pass so that both see the same symbols.  Sink::put(bits, n) receives the
+// n low bits of `bits`, n in 1..27.
+//   DC  entropy_encoder.cpp:97, 715-730: SSSS = bit_width(|diff|); code; then the
+//       low SSSS bits of diff (diff > 0) or of ~|diff| (diff <= 0)
+//   AC  :101-118: (run, v) on every non-zero v, (15, 0) for each full run of 16
+//       zeros that is followed by a non-zero; EOB iff zz[63] == 0;  :732-765 codes
+// Returns false when a value falls outside the tables (SSSS > 11 / > 10).
+template <class Sink>
+__device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, const uint32_t* __restrict__ dc_tab,
+                                             const uint32_t* __restrict__ ac_tab, Sink& sink) {
+    bool ok = true;
+    {
+        const int diff = blk.at(0) - prev_dc;
+        const uint32_t amp = (uint32_t)(diff < 0 ? -diff : diff);
+        uint32_t s = bit_width(amp);
+        if (s > 11) { ok = false; s = 11; }
+        const uint32_t e = dc_tab[s];
+        const uint32_t extra = (diff > 0 ? amp : ~amp) & ((1u << s) - 1u);
+        sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
+    }
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; ++k) {
+        const int v = blk.at(k);
+        if (v != 0) {
+            while (run >= 16) {
+                const uint32_t z = ac_tab[0xF0];
+                sink.put(z & 0xffffu, z >> 16);
+                run -= 16;
+            }
+            const uint32_t amp = (uint32_t)(v < 0 ? -v : v);
+            uint32_t s = bit_width(amp);
+            if (s > 10) { ok = false; s = 10; }
+            const uint32_t e = ac_tab[(run << 4) | s];
+            const uint32_t extra = (v > 0 ? amp : ~amp) & ((1u << s) - 1u);
+            sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
+            run = 0;
+        } else {
+            ++run;
+        }
+    }
+    if (run > 0) {  // zz[63] == 0: trailing zeros (and their ZRLs) collapse into EOB
+        const uint32_t e = ac_tab[0x00];
+        sink.put(e & 0xffffu, e >> 16);
+    }
+    return ok;
+}
+
+struct CountSink {
+    uint32_t bits = 0;
+    __device__ __forceinline__ void put(uint32_t, uint32_t n) { bits += n; }
+};
+
+// MSB-first writer into the LDS window.  `word` is the tile-relative index of
+// the 32-bit word being filled, `nacc` how many of its leading bits are already
+// spoken for.  Words that lie wholly inside this block's bit range are stored
+// plainly; the first and the last word may be shared with neighbouring
+// block-channels and are OR-ed in.
+struct WindowSink {
+    uint32_t* win;
+    uint32_t word, wlo;
+    uint64_t acc;
+    uint32_t nacc;
+    bool first;
+    __device__ __forceinline__ void store(uint32_t v, bool shared_word) {
+        const uint32_t idx = word - wlo;
+        if (idx < kWinWords) {
+            if (shared_word) atomicOr(&win[idx], v);
+            else win[idx] = v;
+        }
+    }
+    __device__ __forceinline__ void put(uint32_t bits, uint32_t n) {
+        acc |= (uint64_t)bits << (64u - nacc - n);
+        nacc += n;
+        if (nacc >= 32) {
+            store((uint32_t)(acc >> 32), first);
+            first = false;
+            acc <<= 32;
+            nacc -= 32;
+            ++word;
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (nacc > 0) store((uint32_t)(acc >> 32), true);
+    }
+};
+
+// Exclusive scan of one value per thread over a 256-thread workgroup.
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* lds4, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    const uint32_t s0 = lds4[0], s1 = lds4[1], s2 = lds4[2], s3 = lds4[3];
+    if (wave > 0) base += s0;
+    if (wave > 1) base += s1;
+    if (wave > 2) base += s2;
+    total = s0 + s1 + s2 + s3;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kEntThreads) void bit_length_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+                                                                 uint32_t n_tiles,
+                                                                 const HuffTables* __restrict__ huff,
+                                                                 uint16_t* __restrict__ len16,
+                                                                 uint32_t* __restrict__ tile_bits,
+                                                                 int32_t* __restrict__ status) {
+    __shared__ HuffLds h;
+    __shared__ uint32_t wsum[4];
+    load_huff(h, huff);
+    __syncthreads();
+    const uint32_t tile = blockIdx.x, img = blockIdx.y;
+    const uint32_t b = tile * kTileBlocks + threadIdx.x;
+    uint32_t bits = 0;
+    if (threadIdx.x < kTileBlocks && b < nbc) {
+        const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
+        BlockRegs blk;
+        load_block(blk, p);
+        const int ch = (int)(b % 3u);
+        const int prev_dc = (b >= 3) ? (int)p[-192] : 0;  // same channel, previous MCU (encoder.cpp:20)
+        CountSink sink;
+        const bool ok = encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
+        if (!ok) atomicExch(status, JEA_ERR_RANGE);
+        bits = sink.bits;
+        len16[(size_t)img * nbc + b] = (uint16_t)bits;
+    }
+    uint32_t total;
+    (void)block_exclusive_scan_256(bits, wsum, total);
+    if (threadIdx.x == 0) tile_bits[(size_t)img * n_tiles + tile] = total;
+}
+
+// One workgroup per image: out[t] = sum of in[0..t-1], total -> img_total[img].
+// Optionally (single image) also finishes the image-level bookkeeping that
+// scan_images_kernel does for batches.
+struct ImageLevel {
+    int mode;               // 0 none, 1 unstuffed bases, 2 final offsets/sizes
+    const uint64_t* img_bits;
+    uint64_t* base_out;     // mode 1: img_ubase, mode 2: d_offsets
+    uint64_t* size_out;     // mode 2: d_sizes
+    uint64_t capacity;
+    uint32_t fixed_bytes;   // mode 2: header + EOI bytes
+    int32_t* status;
+};
+
+__device__ __forceinline__ uint64_t unstuffed_bytes(uint64_t bits) { return (bits + 7) >> 3; }
+__device__ __forceinline__ uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* __restrict__ in, uint32_t n_tiles,
+                                                          uint64_t* __restrict__ out,
+                                                          uint64_t* __restrict__ img_total, ImageLevel lvl) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t img = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint64_t v = (t < n_tiles) ? (uint64_t)in[(size_t)img * n_tiles + t] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t u = __shfl_up(incl, d);
+            if (lane >= d) incl += u;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint64_t base = carry_s;
+        for (int w = 0; w < wave; ++w) base += wave_sum[w];
+        if (t < n_tiles) out[(size_t)img * n_tiles + t] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t total = carry_s;
+        img_total[img] = total;
+        if (gridDim.x == 1 && lvl.mode == 1) {
+            lvl.base_out[0] = 0;
+            if (align_up(unstuffed_bytes(total), 16) > lvl.capacity) atomicExch(lvl.status, JEA_ERR_CAPACITY);
+        } else if (gridDim.x == 1 && lvl.mode == 2) {
+            const uint64_t size = unstuffed_bytes(lvl.img_bits[0]) + total + lvl.fixed_bytes;
+            lvl.base_out[0] = 0;
+            lvl.size_out[0] = size;
+            if (size > lvl.capacity) atomicExch(lvl.status, JEA_ERR_CAPACITY);
+        }
+    }
+}
+
+// Batches: exclusive scan over images of the per-image byte sizes, single workgroup.
+// mode 1: size = align16(unstuffed bytes)                 (img_total = img_bits)
+// mode 2: size = unstuffed bytes + 0xFF count + fixed      (img_total = img_ff), placed at 64-byte steps
+__global__ __launch_bounds__(1024) void scan_images_kernel(uint32_t n_images, const uint64_t* __restrict__ img_total,
+                                                           ImageLevel lvl) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_images; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint64_t size = 0, v = 0;
+        if (i < n_images) {
+            if (lvl.mode == 1) {
+                v = align_up(unstuffed_bytes(img_total[i]), 16);
+            } else {
+                size = unstuffed_bytes(lvl.img_bits[i]) + img_total[i] + lvl.fixed_bytes;
+                v = align_up(size, 64);
+            }
+        }
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t u = __shfl_up(incl, d);
+            if (lane >= d) incl += u;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint64_t base = carry_s;
+        for (int w = 0; w < wave; ++w) base += wave_sum[w];
+        const uint64_t excl = base + incl - v;
+        if (i < n_images) {
+            lvl.base_out[i] = excl;
+            if (lvl.mode == 2) {
+                lvl.size_out[i] = size;
+                if (excl + size > lvl.capacity) atomicExch(lvl.status, JEA_ERR_CAPACITY);
+            } else if (excl + v > lvl.capacity) {
+                atomicExch(lvl.status, JEA_ERR_CAPACITY);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = base + incl;
+        __syncthreads();
+    }
+}
+
+// Owned byte range [b0, b1) of a tile inside its image's unstuffed stream.
+__device__ __forceinline__ void tile_owned_bytes(uint32_t tile, uint32_t n_tiles, const uint64_t* __restrict__ tb,
+                                                 uint64_t img_bits, uint64_t& base_bits, uint64_t& b0, uint64_t& b1) {
+    base_bits = tb[tile];
+    const uint64_t end_bits = (tile + 1 == n_tiles) ? img_bits : tb[tile + 1];
+    b0 = (base_bits + 7) >> 3;
+    b1 = (end_bits + 7) >> 3;
+}
+
+__global__ __launch_bounds__(kEntThreads) void pack_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+                                                           uint32_t n_tiles, const HuffTables* __restrict__ huff,
+                                                           const uint16_t* __restrict__ len16,
+                                                           const uint64_t* __restrict__ tile_base,
+                                                           const uint64_t* __restrict__ img_bits,
+                                                           const uint64_t* __restrict__ img_ubase,
+                                                           uint8_t* __restrict__ unstuffed,
+                                                           uint32_t* __restrict__ tile_ff,
+                                                           const int32_t* __restrict__ status) {
+    __shared__ HuffLds h;
+    __shared__ uint32_t win[kWinWords];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t ff_count;
+    if (*status != 0) return;
+    load_huff(h, huff);
+    const uint32_t tile = blockIdx.x, img = blockIdx.y;
+    const uint32_t b = tile * kTileBlocks + threadIdx.x;
+    // 252 own block-channels + the first MCU of the next tile (threads 252..254)
+    const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
+    const uint32_t my_len = has_block ? len16[(size_t)img * nbc + b] : 0;
+    if (threadIdx.x == 0) ff_count = 0;
+    uint32_t tile_total;
+    const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);  // has barriers: h, ff_count ready
+
+    uint64_t base_bits, b0, b1;
+    tile_owned_bytes(tile, n_tiles, tile_base + (size_t)img * n_tiles, img_bits[img], base_bits, b0, b1);
+    const uint64_t d0 = base_bits >> 5;                      // image-relative dword of window word 0
+    const uint32_t rel_start = (uint32_t)(base_bits & 31) + local_off;
+    const uint32_t n_words = (uint32_t)((b1 * 8 - d0 * 32 + 31) >> 5);  // words that hold owned bytes
+    uint8_t* dst = unstuffed + img_ubase[img];
+
+    BlockRegs blk;
+    int prev_dc = 0;
+    const int ch = (int)(b % 3u);
+    if (has_block) {
+        const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
+        load_block(blk, p);
+        prev_dc = (b >= 3) ? (int)p[-192] : 0;
+    }
+
+    uint32_t my_ff = 0;
+    for (uint32_t wlo = 0; wlo < n_words; wlo += kWinWords) {
+        for (uint32_t i = threadIdx.x; i < kWinWords; i += kEntThreads) win[i] = 0;
+        __syncthreads();
+        if (has_block) {
+            const uint32_t first_word = rel_start >> 5, last_word = (rel_start + my_len - 1) >> 5;
+            if (last_word >= wlo && first_word < wlo + kWinWords) {
+                WindowSink sink{win, first_word, wlo, 0, rel_start & 31u, true};
+                (void)encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
+                sink.finish();
+            }
+        }
+        __syncthreads();
+        const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
+        for (uint32_t i = threadIdx.x; i < words_here; i += kEntThreads) {
+            const uint32_t v = win[i];
+            const uint64_t byte0 = (d0 + wlo + i) * 4;  // image-relative index of the word's first byte
+            const uint32_t bytes[4] = {v >> 24, (v >> 16) & 0xffu, (v >> 8) & 0xffu, v & 0xffu};
+            if (byte0 >= b0 && byte0 + 4 <= b1) {
+                *reinterpret_cast<uint32_t*>(dst + byte0) = __builtin_bswap32(v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) my_ff += (bytes[k] == 0xffu);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t by = byte0 + k;
+                    if (by >= b0 && by < b1) {
+                        dst[by] = (uint8_t)bytes[k];
+                        my_ff += (bytes[k] == 0xffu);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (my_ff) atomicAdd(&ff_count, my_ff);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_ff[(size_t)img * n_tiles + tile] = ff_count;
+}
+
+__global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, const uint64_t* __restrict__ tile_base,
+                                                            const uint64_t* __restrict__ img_bits,
+                                                            const uint64_t* __restrict__ img_ubase,
+                                                            const uint8_t* __restrict__ unstuffed,
+                                                            const uint64_t* __restrict__ tile_ffbase,
+                                                            const uint64_t* __restrict__ img_ff,
+                                                            const uint64_t* __restrict__ offsets, HeaderBytes header,
+                                                            uint32_t header_len, uint32_t with_eoi,
+                                                            uint8_t* __restrict__ out,
+                                                            const int32_t* __restrict__ status) {
+    __shared__ uint32_t wsum[4];
+    if (*status != 0) return;
+    const uint32_t tile = blockIdx.x, img = blockIdx.y;
+    uint64_t base_bits, b0, b1;
+    tile_owned_bytes(tile, n_tiles, tile_base + (size_t)img * n_tiles, img_bits[img], base_bits, b0, b1);
+    const uint8_t* src = unstuffed + img_ubase[img];
+    uint8_t* file = out + offsets[img];
+    uint8_t* dst = file + header_len + tile_ffbase[(size_t)img * n_tiles + tile];  // + source index + 0xFFs before it
+
+    if (tile == 0)
+        for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) file[i] = header.b[i];
+    if (tile + 1 == n_tiles && with_eoi && threadIdx.x == 0) {
+        uint8_t* e = file + header_len + b1 + img_ff[img];
+        e[0] = 0xFF;
+        e[1] = 0xD9;
+    }
+
+    uint64_t carry = 0;  // 0xFF bytes of this tile before the current chunk
+    for (uint64_t c0 = b0; c0 < b1; c0 += (uint64_t)kEntThreads * 16) {
+        const uint64_t i0 = c0 + (uint64_t)threadIdx.x * 16;
+        uint8_t v[16];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] = (i0 + k < b1) ? src[i0 + k] : 0;
+            cnt += (v[k] == 0xFF);
+        }
+        uint32_t total;
+        uint64_t pos = carry + block_exclusive_scan_256(cnt, wsum, total);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (i0 + k < b1) {
+                dst[i0 + k + pos] = v[k];
+                if (v[k] == 0xFF) {
+                    ++pos;
+                    dst[i0 + k + pos] = 0x00;
+                }
+            }
+        }
+        carry += total;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Decode: one wave per image; lane 0 walks the serial Huffman chain (the
+// reference stream has no restart markers, encoder.cpp:121-137), the other lanes
+// stage stream bytes into LDS and store finished blocks.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kStreamWin = 2048;
+
+struct SerialReader {
+    const uint8_t* lds;     // staged raw bytes [base, base + kStreamWin + 16)
+    uint64_t base;          // file-relative index of lds[0]
+    uint64_t pos;           // next raw byte to take
+    uint64_t scan_end;      // file length - 2: stuffing is only removed before this index (bit_stream.cpp:137)
+    uint64_t len;           // file length
+    uint64_t buf;           // bit buffer, MSB first
+    int nbits;              // valid bits in buf
+    int phantom;            // zero bytes appended after the end of the file
+    __device__ __forceinline__ uint32_t raw(uint64_t i) const { return i < len ? lds[i - base] : 0u; }
+    __device__ __forceinline__ void refill() {
+        while (nbits <= 56) {
+            uint32_t b = 0;
+            if (pos < len) {
+                b = raw(pos);
+                // bit_stream.cpp:138: a 0x00 that follows a 0xFF is dropped
+                if (b == 0xFFu && pos < scan_end && raw(pos + 1) == 0x00u) ++pos;
+            } else {
+                ++phantom;
+            }
+            ++pos;
+            buf |= (uint64_t)b << (56 - nbits);
+            nbits += 8;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf >> (64 - n)); }
+    __device__ __forceinline__ void skip(int n) { buf <<= n; nbits -= n; }
+    // true when bits beyond the end of the file have been consumed
+    __device__ __forceinline__ bool past_end() const { return nbits < 8 * phantom; }
+};
+
+// entropy_encoder.cpp:786-806, :845-864
+__device__ __forceinline__ int read_amplitude(SerialReader& r, int ssss) {
+    const uint32_t bits = r.peek(ssss);
+    r.skip(ssss);
+    const uint32_t mask = (1u << ssss) - 1u;
+    if (bits >> (ssss - 1)) return (int)(bits & mask);
+    return -(int)(mask & ~bits);
+}
+
+// The reference grows a candidate code bit by bit from two bits until it equals
+// a code word of that length (entropy_encoder.cpp:767-778, :810-828); for these
+// prefix codes that is the canonical decode: 9-bit table first, then the
+// max-code-per-length walk of T.81 Annex F.2.2.3.  Returns -1 on an invalid code.
+__device__ __forceinline__ int decode_symbol(SerialReader& r, const DecodeTable& t) {
+    const uint32_t e = t.fast[r.peek(9)];
+    if (e) {
+        r.skip((int)(e >> 8));
+        return (int)(e & 0xffu);
+    }
+    const uint32_t p16 = r.peek(16);
+    for (int l = 10; l <= 16; ++l) {
+        const int code = (int)(p16 >> (16 - l));
+        if (code <= t.maxcode[l]) {
+            r.skip(l);
+            return t.vals[code + t.valoff[l]];
+        }
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void entropy_decode_kernel(const uint8_t* __restrict__ scan,
+                                                            const uint64_t* __restrict__ offsets,
+                                                            const uint64_t* __restrict__ sizes, uint32_t n_mcu,
+                                                            const DecodeTables* __restrict__ tables,
+                                                            int16_t* __restrict__ coefs,
+                                                            int32_t* __restrict__ status) {
+    __shared__ DecodeTables t;
+    __shared__ __align__(16) uint8_t stream[kStreamWin + 16];
+    __shared__ int16_t zz[64];
+    __shared__ uint64_t sh_pos;
+    __shared__ int sh_err;
+
+    const uint32_t img = blockIdx.x, lane = threadIdx.x;
+    const uint8_t* file = scan + offsets[img];
+    const uint64_t len = sizes[img];
+    for (uint32_t i = lane; i < sizeof(DecodeTables) / 4; i += 64)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
+    if (lane == 0) { sh_pos = 0; sh_err = 0; }
+    __syncthreads();
+
+    SerialReader rd{stream, 0, 0, len >= 2 ? len - 2 : 0, len, 0, 0, 0};
+    int last_y = 0, last_cb = 0, last_cr = 0;   // encoder.cpp:51
+    uint64_t win_base = ~0ull;
+    const uint32_t nbc = n_mcu * 3;
+    int16_t* out = coefs + (size_t)img * nbc * 64;
+
+    for (uint32_t b = 0; b < nbc; ++b) {
+        // (re)stage the stream window so that lane 0 has >= 1000 raw bytes ahead:
+        // one block-channel is at most 1660 bits, 416 bytes when fully stuffed
+        const uint64_t pos = sh_pos;
+        if (win_base == ~0ull || pos + 1024 > win_base + kStreamWin) {
+            __syncthreads();
+            win_base = pos;
+            for (uint32_t i = lane; i < kStreamWin + 16; i += 64) stream[i] = (win_base + i < len) ? file[win_base + i] : 0;
+        }
+        zz[lane] = 0;
+        __syncthreads();
+        if (lane == 0 && sh_err == 0) {
+            rd.base = win_base;
+            const int ch = (int)(b % 3u);
+            const DecodeTable& dct = t.tab[ch ? 2 : 0];
+            const DecodeTable& act = t.tab[ch ? 3 : 1];
+            int err = 0;
+            rd.refill();
+            const int s = decode_symbol(rd, dct);
+            int diff = 0;
+            if (s < 0 || s > 11) err = JEA_ERR_BAD_STREAM;
+            else if (s > 0) { rd.refill(); diff = read_amplitude(rd, s); }
+            // entropy_encoder.cpp:703-712 symbol loop; :122-144 restores all entries but the LAST
+            int k = 1, processed = 0;
+            bool pending = false;
+            int pend_run = 0, pend_val = 0;
+            while (!err) {
+                rd.refill();
+                const int sym = decode_symbol(rd, act);
+                if (sym < 0) { err = JEA_ERR_BAD_STREAM; break; }
+                int run, val;
+                if (sym == 0x00) { run = 0; val = 0; }
+                else if (sym == 0xF0) { run = 15; val = 0; }
+                else {
+                    run = sym >> 4;
+                    const int ss = sym & 15;
+                    if (ss == 0 || ss > 10) { err = JEA_ERR_BAD_STREAM; break; }
+                    rd.refill();
+                    val = read_amplitude(rd, ss);
+                }
+                if (pending) {  // the previous entry is now known not to be the last: restore it
+                    k += pend_run;
+                    if (k < 64) zz[k] = (int16_t)pend_val;
+                    ++k;
+                }
+                pending = true; pend_run = run; pend_val = val;
+                processed += 1 + run;
+                if (processed > 63) { err = JEA_ERR_BAD_STREAM; break; }
+                if ((run == 0 && val == 0) || processed == 63) break;
+            }
+            if (rd.past_end()) err = JEA_ERR_BAD_STREAM;
+            int last = ch == 0 ? last_y : (ch == 1 ? last_cb : last_cr);
+            last = (int)(int16_t)(diff + last);
+            if (ch == 0) last_y = last; else if (ch == 1) last_cb = last; else last_cr = last;
+            zz[0] = (int16_t)last;
+            // everything before rd.pos - 9 has left the window for good (the bit buffer holds < 9 bytes)
+            sh_pos = rd.pos > 16 ? rd.pos - 16 : 0;
+            if (err) sh_err = err;
+        }
+        __syncthreads();
+        out[(size_t)b * 64 + lane] = zz[lane];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int err = sh_err;
+        if (!err) {
+            // encoder.cpp:63: byte-align, then the next word must be EOI
+            rd.base = win_base;
+            rd.skip(rd.nbits & 7);
+            rd.refill();
+            if (rd.peek(16) != 0xFFD9u || rd.nbits - 16 < 8 * rd.phantom) err = JEA_ERR_NO_EOI;
+        }
+        if (err) atomicCAS(status, 0, err);
+    }
+}
+
+}  // namespace
+
+void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
+                        const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status) {
+    const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
+    const uint32_t n_tiles = tiles_per_image(mcus_per_image);
+    bit_length_kernel<<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, d_len16,
+                                                                               d_tile_bits, d_status);
+}
+
+void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
+                           const HuffTables* d_huff, const EntropyScratch& sc, const HeaderBytes& header,
+                           int header_len, bool with_eoi, uint8_t* d_out, size_t out_capacity, uint64_t* d_offsets,
+                           uint64_t* d_sizes, int32_t* d_status) {
+    const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
+    const uint32_t n_tiles = tiles_per_image(mcus_per_image);
+    const dim3 grid(n_tiles, (unsigned)n_images);
+    const uint32_t n = (uint32_t)n_images;
+
+    bit_length_kernel<<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits, d_status);
+
+    ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
+    scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
+    if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_bits, l1);
+
+    pack_kernel<<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_base, sc.img_bits,
+                                             sc.img_ubase, sc.unstuffed, sc.tile_ff, d_status);
+
+    ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity,
+                  (uint32_t)header_len + (with_eoi ? 2u : 0u), d_status};
+    scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
+    if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, l2);
+
+    stuff_kernel<<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_base, sc.img_bits, sc.img_ubase, sc.unstuffed,
+                                              sc.tile_ffbase, sc.img_ff, d_offsets, header, (uint32_t)header_len,
+                                              with_eoi ? 1u : 0u, d_out, d_status);
+}
+
+void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
+                           size_t n_images, size_t mcus_per_image, const DecodeTables* d_tables, int16_t* d_coefs,
+                           int32_t* d_status) {
+    entropy_decode_kernel<<<(unsigned)n_images, 64, 0, s>>>(d_scan, d_offsets, d_sizes, (uint32_t)mcus_per_image,
+                                                           d_tables, d_coefs, d_status);
+}
+
+}  // namespace jea

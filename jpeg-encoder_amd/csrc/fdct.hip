@@ -1,0 +1,350 @@
+// Fused forward kernel: block fetch with edge replication + RGB->YCbCr + level
+// shift + separable 8x8 forward DCT + quantise + zig-zag, one pass over the
+// image, plus the matching inverse kernel and the per-pixel colour kernels.
+//
+// Arithmetic contract (bit-exact with the reference, paths relative to its root):
+//   colour      jpeg/src/colour_mapping.cpp:44-67 / :69-92   double, left to right
+//   level shift jpeg/src/discrete_cosine_transform.cpp:13-27
+//   FDCT        :77-88, :103-124   float, every product and sum rounded, no FMA,
+//               8-term sums in index order, scale applied after the sum
+//   IDCT        :90-101, :126-156  (scale*cos) pre-multiplied, clamp, truncation
+//   quantise    jpeg/src/quantiser.cpp:57-70   float divide, +0.5 and floor in double
+//   dequantise  :72-85
+//   zig-zag     jpeg/src/entropy_encoder.cpp:15-92
+//   edges       jpeg/src/block_grid.cpp:8-28 (replicate), :87-99 (crop)
+// This file must be compiled with -ffp-contract=off.
+//
+// Mapping to the machine: a workgroup of 192 threads owns 64 consecutive MCUs.
+// Wave w (64 lanes) is channel w (Y, Cb, Cr) and lane l is MCU l, so channel
+// dependent constants are wave-uniform (scalar registers) and one thread carries
+// one whole 8x8 block-channel in registers through both DCT passes -- no
+// cross-lane traffic in the transform.  Pixels come in through LDS with
+// coalesced 8-byte loads of the 8 row strips; coefficient blocks go out through
+// LDS so that the 24 KiB the workgroup produces is stored as one contiguous run
+// of 16-byte stores.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "tables.h"
+
+namespace jea {
+
+namespace {
+
+constexpr int kMcusPerGroup = 64;
+constexpr int kFdctThreads = 192;
+
+// colour_mapping.cpp:48-51: floor(in + 0.5), clamp to [0, 255]
+__device__ __forceinline__ double round_to_range(double v) {
+    v = floor(v + 0.5);
+    v = (0.0 < v) ? v : 0.0;
+    v = (255.0 < v) ? 255.0 : v;
+    return v;
+}
+
+// One output channel of RGBToYCbCrMapper::applyMapping, colour_mapping.cpp:52-60.
+// Each formula there has the shape ((k + a*r) + b*g) + c*b evaluated left to
+// right in double; subtracting a product equals adding the product of the
+// negated constant, so one expression serves the three channels:
+//   Y  : k = 0,   a =  0.299,    b =  0.587,    c =  0.114
+//   Cb : k = 128, a = -0.168736, b = -0.331264, c =  0.5
+//   Cr : k = 128, a =  0.5,      b = -0.418688, c = -0.081312
+__device__ __forceinline__ double colour_forward(double k, double a, double b, double c, double r, double g,
+                                                 double bl) {
+    return round_to_range(((k + a * r) + b * g) + c * bl);
+}
+
+__device__ __forceinline__ void colour_constants(int channel, double& k, double& a, double& b, double& c) {
+    k = channel == 0 ? 0.0 : 128.0;
+    a = channel == 0 ? 0.299 : (channel == 1 ? -0.168736 : 0.5);
+    b = channel == 0 ? 0.587 : (channel == 1 ? -0.331264 : -0.418688);
+    c = channel == 0 ? 0.114 : (channel == 1 ? 0.5 : -0.081312);
+}
+
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) {
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+}
+
+template <bool kFast>
+__global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t* __restrict__ rgb, int width,
+                                                                  int height, int blocks_w, uint32_t n_mcu,
+                                                                  size_t image_bytes, QuantTables q,
+                                                                  int16_t* __restrict__ coefs) {
+    // rows of the 64 MCUs: [row 0..7][mcu 0..63][8 px * 3 B]
+    __shared__ __align__(16) uint8_t lds_in[8 * kMcusPerGroup * 24];
+    // finished blocks: [mcu][channel][128 B], 16-byte chunks rotated by the block index
+    __shared__ __align__(16) uint8_t lds_out[kFdctThreads * 128];
+
+    const int tid = threadIdx.x;
+    const uint32_t g0 = blockIdx.x * kMcusPerGroup;
+    const uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
+    const uint32_t mcus_here = (n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup;
+
+    if (kFast) {
+        // width % 8 == 0: every MCU row strip is 24 in-bounds bytes at an 8-byte
+        // aligned address; thread t moves piece t%3 of MCU t/3 for each of the 8 rows.
+        const int m = tid / 3, part = tid - 3 * m;
+        if ((uint32_t)m < mcus_here) {
+            const uint32_t mcu = g0 + m;
+            const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+            uint2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                int y = (int)by * 8 + r;
+                y = y < height ? y : height - 1;  // bottom edge: repeat the last row
+                v[r] = *reinterpret_cast<const uint2*>(img + ((size_t)y * width + bx * 8) * 3 + part * 8);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) *reinterpret_cast<uint2*>(lds_in + r * 1536 + tid * 8) = v[r];
+        }
+    } else {
+        // any width: byte gather with the x and y clamps of block_grid.cpp:16-26
+        for (int i = tid; i < 8 * kMcusPerGroup * 24; i += kFdctThreads) {
+            const int r = i / 1536, rem = i - r * 1536;
+            const int m = rem / 24, byte = rem - m * 24;
+            const int px = byte / 3, comp = byte - px * 3;
+            if ((uint32_t)m < mcus_here) {
+                const uint32_t mcu = g0 + m;
+                const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+                int y = (int)by * 8 + r, x = (int)bx * 8 + px;
+                y = y < height ? y : height - 1;
+                x = x < width ? x : width - 1;
+                lds_in[i] = img[((size_t)y * width + x) * 3 + comp];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int channel = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = tid & 63;
+    const uint32_t j = (uint32_t)m * 3 + (uint32_t)channel;  // block index inside the group
+    if ((uint32_t)m < mcus_here) {
+        double ck, ca, cb, cc;
+        colour_constants(channel, ck, ca, cb, cc);
+
+        // Row pass, discrete_cosine_transform.cpp:103-112: for image row y
+        //   row[u][y] = s(u) * sum_x C[u][x] * f[x]
+        float row[8][8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            const uint2* src = reinterpret_cast<const uint2*>(lds_in + y * 1536 + m * 24);
+            const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
+            const uint32_t d[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+            float f[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
+                const double r = (double)((d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu);
+                const double g = (double)((d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu);
+                const double b = (double)((d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu);
+                // u8 result, then "- 128" into int8 (:13-19), then float(int8) in the sum
+                f[p] = (float)colour_forward(ck, ca, cb, cc, r, g, b) - 128.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float acc = cos_c(u, 0) * f[0];
+#pragma unroll
+                for (int x = 1; x < 8; ++x) acc += cos_c(u, x) * f[x];
+                row[u][y] = scale_s(u) * acc;
+            }
+        }
+
+        // Column pass :114-124 and quantiser.cpp:57-70:
+        //   out[8v+u] = s(v) * sum_y C[v][y] * row[u][y];  q = floor(0.5 + double(out / Q))
+        const float* qt = channel == 0 ? q.lum : q.chr;
+        int qv[64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                float acc = cos_c(v, 0) * row[u][0];
+#pragma unroll
+                for (int y = 1; y < 8; ++y) acc += cos_c(v, y) * row[u][y];
+                const float o = scale_s(v) * acc;
+                const float quot = o / qt[8 * v + u];
+                qv[8 * v + u] = (int)floor(0.5 + (double)quot);
+            }
+        }
+
+        // zig-zag (entropy_encoder.cpp:15-77) and hand-over through LDS
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            uint4 chunk;
+            chunk.x = pack16(qv[kZigzag[8 * k8 + 0]], qv[kZigzag[8 * k8 + 1]]);
+            chunk.y = pack16(qv[kZigzag[8 * k8 + 2]], qv[kZigzag[8 * k8 + 3]]);
+            chunk.z = pack16(qv[kZigzag[8 * k8 + 4]], qv[kZigzag[8 * k8 + 5]]);
+            chunk.w = pack16(qv[kZigzag[8 * k8 + 6]], qv[kZigzag[8 * k8 + 7]]);
+            *reinterpret_cast<uint4*>(lds_out + j * 128 + ((((uint32_t)k8 + j) & 7u) << 4)) = chunk;
+        }
+    }
+    __syncthreads();
+
+    // [mcu][channel][64] int16 of this group is one contiguous run in memory
+    uint4* out = reinterpret_cast<uint4*>(coefs + ((size_t)blockIdx.y * n_mcu + g0) * 192);
+    const uint32_t n_chunks = mcus_here * 3 * 8;
+    for (uint32_t i = tid; i < n_chunks; i += kFdctThreads) {
+        const uint32_t jj = i >> 3, kk = i & 7u;
+        out[i] = *reinterpret_cast<const uint4*>(lds_out + jj * 128 + (((kk + jj) & 7u) << 4));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Inverse: de-zigzag + dequantise + IDCT + level unshift + YCbCr->RGB + crop.
+// Same thread mapping as the forward kernel; the three channel planes of the 64
+// MCUs meet in LDS, then each thread colour-converts whole pixels.
+// ---------------------------------------------------------------------------
+
+// colour_mapping.cpp:77-85; (C - 128) is formed in integer arithmetic first.
+__device__ __forceinline__ void colour_inverse(int Y, int Cb, int Cr, uint8_t& r, uint8_t& g, uint8_t& b) {
+    const double y = (double)Y, cb = (double)(Cb - 128), cr = (double)(Cr - 128);
+    r = (uint8_t)round_to_range(y + 1.402 * cr);
+    g = (uint8_t)round_to_range((y - 0.344136 * cb) - 0.714136 * cr);
+    b = (uint8_t)round_to_range(y + 1.772 * cb);
+}
+
+constexpr float inv_c(int u, int x) { return scale_s(u) * cos_c(u, x); }  // fl32(s(u) * C[u][x]), :131,:142
+
+__global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_t* __restrict__ coefs, int width,
+                                                                    int height, int blocks_w, uint32_t n_mcu,
+                                                                    size_t image_bytes, QuantTables q,
+                                                                    uint8_t* __restrict__ rgb) {
+    __shared__ __align__(16) uint8_t lds_coef[kFdctThreads * 128];  // rotated chunks, as in the forward kernel
+    __shared__ __align__(16) uint8_t lds_px[3 * kMcusPerGroup * 64 + 16];  // [channel][mcu][64] u8
+
+    const int tid = threadIdx.x;
+    const uint32_t g0 = blockIdx.x * kMcusPerGroup;
+    uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
+    const uint32_t mcus_here = (n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup;
+
+    const uint4* in = reinterpret_cast<const uint4*>(coefs + ((size_t)blockIdx.y * n_mcu + g0) * 192);
+    const uint32_t n_chunks = mcus_here * 3 * 8;
+    for (uint32_t i = tid; i < n_chunks; i += kFdctThreads) {
+        const uint32_t jj = i >> 3, kk = i & 7u;
+        *reinterpret_cast<uint4*>(lds_coef + jj * 128 + (((kk + jj) & 7u) << 4)) = in[i];
+    }
+    __syncthreads();
+
+    const int channel = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = tid & 63;
+    const uint32_t j = (uint32_t)m * 3 + (uint32_t)channel;
+    if ((uint32_t)m < mcus_here) {
+        const float* qt = channel == 0 ? q.lum : q.chr;
+        // de-zigzag (entropy_encoder.cpp:79-92) and dequantise (quantiser.cpp:72-85)
+        float deq[64];
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const uint4 c4 = *reinterpret_cast<const uint4*>(lds_coef + j * 128 + ((((uint32_t)k8 + j) & 7u) << 4));
+            const uint32_t w[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * k8 + e;
+                const int v = (int)(int16_t)(w[e >> 1] >> (16 * (e & 1)));
+                deq[kZigzag[k]] = (float)v * qt[kZigzag[k]];
+            }
+        }
+        // Row pass :126-135: tmp[x][v] = sum_u (s(u)C[u][x]) * src[u + 8v]
+        float tmp[8][8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                float acc = inv_c(0, x) * deq[8 * v];
+#pragma unroll
+                for (int u = 1; u < 8; ++u) acc += inv_c(u, x) * deq[u + 8 * v];
+                tmp[x][v] = acc;
+            }
+        }
+        // Column pass :136-156: out[8y+x] = clamp/truncate(sum_v (s(v)C[v][y]) * tmp[x][v]); +128 (:21-27)
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            uint32_t packed[2] = {0, 0};
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                float acc = inv_c(0, y) * tmp[x][0];
+#pragma unroll
+                for (int v = 1; v < 8; ++v) acc += inv_c(v, y) * tmp[x][v];
+                int o;
+                if (acc < -128.0f) o = -128;
+                else if (acc > 127.0f) o = 127;
+                else o = (int)acc;
+                packed[x >> 2] |= (uint32_t)(o + 128) << (8 * (x & 3));
+            }
+            *reinterpret_cast<uint2*>(lds_px + (channel * kMcusPerGroup + m) * 64 + y * 8) = make_uint2(packed[0], packed[1]);
+        }
+    }
+    __syncthreads();
+
+    // colour conversion and cropped store: work item = (row r, mcu m, pixel p),
+    // ordered so that consecutive threads write consecutive pixels of a row strip
+    for (uint32_t i = tid; i < 8u * mcus_here * 8u; i += kFdctThreads) {
+        const uint32_t r = i / (mcus_here * 8u), rem = i - r * (mcus_here * 8u);
+        const uint32_t mm = rem >> 3, p = rem & 7u;
+        const uint32_t mcu = g0 + mm;
+        const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+        const int y = (int)by * 8 + (int)r, x = (int)bx * 8 + (int)p;
+        if (y < height && x < width) {
+            const int Y = lds_px[(0 * kMcusPerGroup + mm) * 64 + r * 8 + p];
+            const int Cb = lds_px[(1 * kMcusPerGroup + mm) * 64 + r * 8 + p];
+            const int Cr = lds_px[(2 * kMcusPerGroup + mm) * 64 + r * 8 + p];
+            uint8_t rr, gg, bb;
+            colour_inverse(Y, Cb, Cr, rr, gg, bb);
+            uint8_t* dst = img + ((size_t)y * width + x) * 3;
+            dst[0] = rr; dst[1] = gg; dst[2] = bb;
+        }
+    }
+}
+
+__global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, size_t n, uint8_t* __restrict__ ycc) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            double ck, ca, cb, cc;
+            colour_constants(ch, ck, ca, cb, cc);
+            ycc[3 * i + ch] = (uint8_t)colour_forward(ck, ca, cb, cc, r, g, b);
+        }
+    }
+}
+
+__global__ void ycbcr_to_rgb_kernel(const uint8_t* __restrict__ ycc, size_t n, uint8_t* __restrict__ rgb) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint8_t r, g, b;
+        colour_inverse(ycc[3 * i], ycc[3 * i + 1], ycc[3 * i + 2], r, g, b);
+        rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b;
+    }
+}
+
+}  // namespace
+
+void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
+                       const QuantTables& q, int16_t* d_coefs) {
+    const int bw = (width + 7) / 8, bh = (height + 7) / 8;
+    const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
+    const size_t image_bytes = (size_t)3 * width * height;
+    const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
+    const bool fast = (width % 8 == 0) && ((reinterpret_cast<uintptr_t>(d_rgb) & 7u) == 0);
+    if (fast)
+        fdct_quant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs);
+    else
+        fdct_quant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs);
+}
+
+void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
+                         const QuantTables& q, uint8_t* d_rgb) {
+    const int bw = (width + 7) / 8, bh = (height + 7) / 8;
+    const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
+    const size_t image_bytes = (size_t)3 * width * height;
+    const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
+    idct_dequant_kernel<<<grid, kFdctThreads, 0, s>>>(d_coefs, width, height, bw, n_mcu, image_bytes, q, d_rgb);
+}
+
+void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc) {
+    const unsigned grid = (unsigned)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);
+    rgb_to_ycbcr_kernel<<<grid ? grid : 1, 256, 0, s>>>(d_rgb, n_pixels, d_ycc);
+}
+void launch_ycbcr_to_rgb(hipStream_t s, const uint8_t* d_ycc, size_t n_pixels, uint8_t* d_rgb) {
+    const unsigned grid = (unsigned)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);
+    ycbcr_to_rgb_kernel<<<grid ? grid : 1, 256, 0, s>>>(d_ycc, n_pixels, d_rgb);
+}
+
+}  // namespace jea

@@ -1,0 +1,87 @@
+// Host-callable launchers of the gfx950 kernels.  Each launcher only enqueues on
+// the given stream; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace jea {
+
+// Passed to kernels by value: it then lives in the kernarg segment, where
+// wave-uniform reads at compile-time offsets become scalar loads.
+struct QuantTables {
+    float lum[64];  // natural order, float(Q) as the reference converts it
+    float chr[64];  // (quantiser.cpp:61,66,76,81)
+};
+
+// Huffman code tables: entry = (length << 16) | code word, indexed by symbol.
+struct HuffTables {
+    uint32_t dc[2][12];   // [0 = luminance, 1 = chrominance][SSSS]
+    uint32_t ac[2][256];  // [class][RRRRSSSS]; 0x00 = EOB, 0xF0 = ZRL
+};
+
+// Huffman decode tables, one per (class, DC/AC): index 0 lum-DC, 1 lum-AC,
+// 2 chr-DC, 3 chr-AC.  fast[] resolves codes of up to 9 bits from a 9-bit prefix
+// ((length << 8) | symbol, 0 = longer); longer codes use the per-length
+// max-code walk: symbol = vals[code + valoff[length]] when code <= maxcode[length].
+struct DecodeTable {
+    uint16_t fast[512];
+    int32_t maxcode[18];  // -1 when no code has that length
+    int32_t valoff[18];
+    uint8_t vals[256];
+};
+struct DecodeTables {
+    DecodeTable tab[4];
+};
+
+struct HeaderBytes {
+    uint8_t b[608];  // 607 used
+};
+
+// Entropy coding works on tiles of kTileBlocks consecutive block-channels of
+// one image (84 MCUs); tiles never straddle images.
+constexpr int kTileBlocks = 252;
+
+inline uint32_t tiles_per_image(size_t mcus_per_image) {
+    return (uint32_t)((mcus_per_image * 3 + kTileBlocks - 1) / kTileBlocks);
+}
+
+// Device-side bookkeeping of one encode pass; all arrays are caller-provided
+// scratch.  n_tiles = tiles per image, n = images.
+struct EntropyScratch {
+    uint16_t* len16;        // [n][mcus*3]      bits per block-channel
+    uint32_t* tile_bits;    // [n][n_tiles]
+    uint64_t* tile_base;    // [n][n_tiles]     exclusive scan of tile_bits within the image
+    uint32_t* tile_ff;      // [n][n_tiles]     0xFF bytes among the tile's owned bytes
+    uint64_t* tile_ffbase;  // [n][n_tiles]     exclusive scan of tile_ff within the image
+    uint64_t* img_bits;     // [n]
+    uint64_t* img_ubase;    // [n]  byte offset of the image's unstuffed stream in `unstuffed`
+    uint64_t* img_ff;       // [n]
+    uint8_t* unstuffed;     // packed, not yet byte-stuffed streams
+    size_t unstuffed_capacity;
+};
+
+void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
+                       const QuantTables& q, int16_t* d_coefs);
+
+void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
+                        const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status);
+
+// bit-length pass -> scans -> pack -> stuff.  header_len is 0 or 607; with_eoi appends FFD9.
+void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
+                           const HuffTables* d_huff, const EntropyScratch& sc, const HeaderBytes& header,
+                           int header_len, bool with_eoi, uint8_t* d_out, size_t out_capacity,
+                           uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
+
+void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
+                           size_t n_images, size_t mcus_per_image, const DecodeTables* d_tables, int16_t* d_coefs,
+                           int32_t* d_status);
+
+void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
+                         const QuantTables& q, uint8_t* d_rgb);
+
+void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc);
+void launch_ycbcr_to_rgb(hipStream_t s, const uint8_t* d_ycc, size_t n_pixels, uint8_t* d_rgb);
+
+}  // namespace jea
