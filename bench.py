@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: baseline-JPEG encode throughput (MPix/s, q=75) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one encode of `--batch` (default 1) device-resident 3840x2160 RGB
+images at q=75 through the whole hot path (fused colour+FDCT+quantise+zigzag
+kernel, bit-length pass, scans, pack, byte stuffing, header and EOI); input and
+output stay in HBM.  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; images are sharded by rank, there is no data-path
+collective, and the reported value is all ranks' pixels over the slowest rank's
+time (weak scaling).
+
+The JSON line also carries
+  roofline      the fused FDCT kernel's algorithmic bytes (9 B/px) over its
+                average launch duration, measured with HIP events on the
+                library's stream, against the 8 TB/s HBM peak
+  cpu_baseline  the CPU restatement of the reference encoder (oracle/), one
+                thread, timed on this host on a bounded sample (rank 0, N=1)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W, H, QUALITY = 3840, 2160, 75
+HBM_PEAK_GBS = 8000.0
+K1_BYTES_PER_PIXEL = 9.0  # 3 B RGB read + 3 x int16 coefficient write
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="images per step")
+    ap.add_argument("--mode", type=int, default=0, help="0 smooth gradients + noise, 1 uniform noise")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=10, help="images of the CPU sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("jpeg-encoder_amd")
+    binding = pkg.binding
+    ctx = pkg.Context(local_rank)
+    dev = ctx.tdev
+    lum, chrom = binding.quant_tables(QUALITY)
+
+    # synthetic input, resident in HBM before the timed region; every rank gets its own images
+    import pyoracle as po  # generator + checker only; nothing timed on the GPU side calls it
+
+    imgs = np.stack([po.gen_image(W, H, args.mode, 1234 + rank * args.batch + i) for i in range(args.batch)])
+    d_rgb = ctx.to_device(imgs.reshape(-1))
+    cap = args.batch * (3 * W * H // 2 + (1 << 20)) if args.mode == 0 else args.batch * binding.max_jpeg_bytes(W, H)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_offsets = torch.zeros(args.batch, dtype=torch.int64, device=dev)
+    d_sizes = torch.zeros(args.batch, dtype=torch.int64, device=dev)
+    d_status = torch.zeros(16, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        ctx.encode_batch_async(d_rgb, args.batch, W, H, lum, chrom, d_out, d_offsets, d_sizes, d_status)
+
+    # parity gate before timing: the first image's file must equal the oracle's, byte for byte
+    step()
+    ctx.synchronize()
+    assert int(d_status[0].item()) == 0, "encode reported status %d" % int(d_status[0].item())
+    off0, size0 = int(d_offsets[0].item()), int(d_sizes[0].item())
+    gpu_file = d_out[off0: off0 + size0].cpu().numpy().tobytes()
+    parity = gpu_file == po.encode(imgs[0], QUALITY)
+    if not parity:
+        raise SystemExit("bench: GPU JPEG differs from the oracle's; refusing to report a number")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(d_status[0].item()) == 0
+
+    pixels_per_step = args.batch * W * H
+    value = world * args.steps * pixels_per_step / elapsed / 1e6
+
+    # ---- roofline of the fused colour+FDCT+quantise+zigzag kernel, live, on the library's stream ----
+    ext = torch.cuda.ExternalStream(ctx.stream_handle, device=dev)
+    d_coefs = torch.empty(args.batch * binding.n_mcu(W, H) * 192, dtype=torch.int16, device=dev)
+    reps = 50
+    with torch.cuda.stream(ext):
+        for _ in range(5):
+            ctx.fdct_quant_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ctx.fdct_quant_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs)
+        e1.record()
+    ctx.synchronize()
+    k1_ms = e0.elapsed_time(e1) / reps
+    k1_bytes = K1_BYTES_PER_PIXEL * pixels_per_step
+    achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+    roofline = {"kernel": "fdct_quant_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(k1_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(k1_bytes)}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n = max(1, args.cpu_images)
+        t0 = time.perf_counter()
+        for i in range(n):
+            po.encode(imgs[i % args.batch], QUALITY)
+        dt = time.perf_counter() - t0
+        cpu_baseline = {"value": round(n * W * H / dt / 1e6, 2), "unit": "MPix/s", "cores": 1, "kind": "port",
+                        "sample": "%d x %dx%d q=%d encodes of the same synthetic image(s), single thread, "
+                                  "oracle/jpeg_oracle.c (byte-identical to the reference)" % (n, W, H, QUALITY)}
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out = {
+            "metric": "encode MPix/s (q=75)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic %s RGB8 (mt19937 seed 1234+), resident in HBM" % ("smooth" if args.mode == 0 else "noise"),
+            "config": {"workload": "single 3840x2160 RGB image encode at q=75 per step" if args.batch == 1 else
+                       "%d x 3840x2160 RGB images encoded at q=75 per step" % args.batch,
+                       "images_per_step": args.batch, "width": W, "height": H, "quality": QUALITY,
+                       "jpeg_bytes_image0": size0, "byte_identical_to_oracle": parity,
+                       "sharding": "images by rank, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

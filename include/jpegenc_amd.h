@@ -134,6 +134,11 @@ int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t wi
 int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
                    const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs);
 
+/* jea_fdct_quant without the final synchronisation: enqueues on the context's
+ * stream and returns (for callers that time or pipeline the kernel themselves). */
+int jea_fdct_quant_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                         const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs);
+
 /* Bit length of every block-channel ([image][mcu][channel] order) with the DC
  * prediction chain of encoder.cpp:20 restarted per image.  Replaces
  * entropy_encoder.cpp:94-120 and the length side of :715-765.

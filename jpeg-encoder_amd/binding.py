@@ -16,7 +16,7 @@ EXPORTS = [
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_decode_batch", "jea_decode_host",
-    "jea_fdct_quant", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
+    "jea_fdct_quant", "jea_fdct_quant_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
     "jea_rgb_to_ycbcr", "jea_ycbcr_to_rgb",
     "jea_malloc", "jea_free", "jea_memcpy_h2d", "jea_memcpy_d2h",
 ]
@@ -64,6 +64,7 @@ def load_library():
     lib.jea_decode_batch.argtypes = [vp, vp, vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_decode_host.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_fdct_quant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_fdct_quant_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_block_bit_lengths.argtypes = [vp, vp, sz, sz, vp]
     lib.jea_entropy_encode.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp]
     lib.jea_entropy_decode.argtypes = [vp, vp, vp, vp, sz, sz, vp]
@@ -162,6 +163,10 @@ class Context:
         self._check(self.lib.jea_fdct_quant(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
                                             chrom.ctypes.data, coefs.data_ptr()))
         return coefs
+
+    def fdct_quant_async(self, d_rgb, n_images, w, h, lum, chrom, d_coefs):
+        self._check(self.lib.jea_fdct_quant_async(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
+                                                  chrom.ctypes.data, d_coefs.data_ptr()))
 
     def idct_dequant(self, d_coefs, n_images, w, h, lum, chrom):
         rgb = self.empty(n_images * 3 * w * h, self.torch.uint8)

@@ -377,8 +377,8 @@ int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uin
 
 // ---- stage entry points -----------------------------------------------------
 
-int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
-                   const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs) {
+int jea_fdct_quant_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                         const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs) {
     if (!ctx) return JEA_ERR_INVALID_ARG;
     if (!d_rgb || !d_coefs || n_images == 0 || n_images > 65535 || !valid_dims(width, height) ||
         !tables_ok(lum_q, chr_q))
@@ -386,6 +386,13 @@ int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t
     JEA_HIP(ctx, hipSetDevice(ctx->device));
     launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs);
     JEA_HIP(ctx, hipGetLastError());
+    return JEA_OK;
+}
+
+int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                   const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs) {
+    const int rc = jea_fdct_quant_async(ctx, d_rgb, n_images, width, height, lum_q, chr_q, d_coefs);
+    if (rc) return rc;
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JEA_OK;
 }
