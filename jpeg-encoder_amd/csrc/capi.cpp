@@ -118,6 +118,11 @@ QuantTables to_float_tables(const uint16_t lum_q[64], const uint16_t chr_q[64]) 
     for (int i = 0; i < 64; ++i) {
         q.lum[i] = (float)lum_q[i];
         q.chr[i] = (float)chr_q[i];
+        const int t = 8 * (i & 7) + (i >> 3);
+        q.lum_t[t] = q.lum[i];
+        q.chr_t[t] = q.chr[i];
+        q.rlum_t[t] = 1.0f / q.lum[i];
+        q.rchr_t[t] = 1.0f / q.chr[i];
     }
     return q;
 }

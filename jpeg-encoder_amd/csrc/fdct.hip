@@ -65,15 +65,87 @@ __device__ __forceinline__ uint32_t pack16(int lo, int hi) {
     return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
 }
 
+// Forward-transform constants with the scale folded in where that is exact:
+// s(u) = 0.5 for u > 0 is a power of two, so  0.5 * sum_x C[u][x] f[x]  equals
+// sum_x (0.5 C[u][x]) f[x]  bit for bit (scaling by two commutes with every
+// rounding; nothing here comes near the subnormal range).  Row u = 0 has
+// C = 1 exactly, so its sum needs no products and keeps the final multiply by
+// s(0) = 0.5/sqrt(2), which is not a power of two.
+constexpr float fwd_c(int u, int x) { return u == 0 ? 1.0f : 0.5f * cos_c(u, x); }
+
+// Row pass of discrete_cosine_transform.cpp:103-112 for image row y of the block:
+//   row[u][y] = s(u) * (((C[u][0] f[0] + C[u][1] f[1]) + ...) + C[u][7] f[7])
+__device__ __forceinline__ void fdct_row(const float (&f)[8], int y, float (&row)[8][8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float acc = fwd_c(u, 0) * f[0];
+#pragma unroll
+        for (int x = 1; x < 8; ++x) acc += fwd_c(u, x) * f[x];
+        row[u][y] = (u == 0) ? scale_s(0) * acc : acc;
+    }
+}
+
+// Column pass :114-124 for horizontal frequency u: o[v] = out[8v+u].
+__device__ __forceinline__ void fdct_col(const float (&row)[8][8], int u, float (&o)[8]) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        float acc = fwd_c(v, 0) * row[u][0];
+#pragma unroll
+        for (int y = 1; y < 8; ++y) acc += fwd_c(v, y) * row[u][y];
+        o[v] = (v == 0) ? scale_s(0) * acc : acc;
+    }
+}
+
+// quantiser.cpp:57-70, literally: IEEE float divide, then 0.5 + and floor in double.
+__device__ __forceinline__ int quantise_exact(float o, float q) {
+    const float quot = o / q;
+    return (int)floor(0.5 + (double)quot);
+}
+
+// The same value from a reciprocal multiply.  t = o * rq differs from the
+// correctly rounded quotient by less than |t| * 2^-22 (rq = RN(1/q) and the
+// product each contribute at most 2^-24 relative, the reference's own division
+// another 2^-24), so floor(t + 0.5) is the reference's result unless t lies
+// within that distance of a half-integer; such lanes are flagged and redone
+// with quantise_exact.  v_cvt_rpi_i32_f32 is floor(x + 0.5) as an integer; its
+// own rounding of x + 0.5 is covered by the same margin.
+__device__ __forceinline__ int quantise_fast(float o, float rq, bool& ambiguous) {
+    const float t = o * rq;
+    int n;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(n) : "v"(t));
+    const float e = __builtin_fabsf(__builtin_amdgcn_fractf(t) - 0.5f);
+    ambiguous = e < __builtin_fabsf(t) * 0x1p-20f + 0x1p-22f;
+    return n;
+}
+
+// Quantises the eight coefficients out[8v+u], v = 0..7, of one column u.
+__device__ __forceinline__ void quantise_col(const float (&o)[8], const float* __restrict__ qt,
+                                             const float* __restrict__ rqt, int u, int* __restrict__ qv) {
+    bool any = false;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        bool amb;
+        qv[8 * v + u] = quantise_fast(o[v], rqt[8 * u + v], amb);  // tables are stored [u][v]
+        any |= amb;
+    }
+    if (__builtin_expect(any, 0)) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) qv[8 * v + u] = quantise_exact(o[v], qt[8 * u + v]);
+    }
+}
+
 template <bool kFast>
 __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t* __restrict__ rgb, int width,
                                                                   int height, int blocks_w, uint32_t n_mcu,
                                                                   size_t image_bytes, QuantTables q,
                                                                   int16_t* __restrict__ coefs) {
-    // rows of the 64 MCUs: [row 0..7][mcu 0..63][8 px * 3 B]
-    __shared__ __align__(16) uint8_t lds_in[8 * kMcusPerGroup * 24];
-    // finished blocks: [mcu][channel][128 B], 16-byte chunks rotated by the block index
-    __shared__ __align__(16) uint8_t lds_out[kFdctThreads * 128];
+    // One buffer, used twice: first the pixel rows of the 64 MCUs
+    // ([row 0..7][mcu 0..63][8 px * 3 B], 12 KiB), then, after every wave has
+    // finished its row pass, the finished blocks ([mcu][channel][128 B] with the
+    // 16-byte chunks rotated by the block index, 24 KiB).
+    __shared__ __align__(16) uint8_t lds[kFdctThreads * 128];
+    uint8_t* const lds_in = lds;
+    uint8_t* const lds_out = lds;
 
     const int tid = threadIdx.x;
     const uint32_t g0 = blockIdx.x * kMcusPerGroup;
@@ -118,13 +190,11 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
     const int channel = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = tid & 63;
     const uint32_t j = (uint32_t)m * 3 + (uint32_t)channel;  // block index inside the group
-    if ((uint32_t)m < mcus_here) {
+    const bool active = (uint32_t)m < mcus_here;
+    float row[8][8];
+    if (active) {
         double ck, ca, cb, cc;
         colour_constants(channel, ck, ca, cb, cc);
-
-        // Row pass, discrete_cosine_transform.cpp:103-112: for image row y
-        //   row[u][y] = s(u) * sum_x C[u][x] * f[x]
-        float row[8][8];
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
             const uint2* src = reinterpret_cast<const uint2*>(lds_in + y * 1536 + m * 24);
@@ -137,35 +207,26 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
                 const double r = (double)((d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu);
                 const double g = (double)((d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu);
                 const double b = (double)((d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu);
-                // u8 result, then "- 128" into int8 (:13-19), then float(int8) in the sum
-                f[p] = (float)colour_forward(ck, ca, cb, cc, r, g, b) - 128.0f;
+                // floor(v + 0.5) is an integer in [-1, 256]: exact as a float, so the clamp
+                // to [0, 255] (:49-51) can be done there; then "- 128" into int8 (:13-19)
+                const float rounded = (float)floor((((ck + ca * r) + cb * g) + cc * b) + 0.5);
+                f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float acc = cos_c(u, 0) * f[0];
-#pragma unroll
-                for (int x = 1; x < 8; ++x) acc += cos_c(u, x) * f[x];
-                row[u][y] = scale_s(u) * acc;
-            }
+            fdct_row(f, y, row);
         }
+    }
+    __syncthreads();  // every wave is done with lds_in: the buffer becomes lds_out
 
-        // Column pass :114-124 and quantiser.cpp:57-70:
-        //   out[8v+u] = s(v) * sum_y C[v][y] * row[u][y];  q = floor(0.5 + double(out / Q))
-        const float* qt = channel == 0 ? q.lum : q.chr;
+    if (active) {
+        const float* qt = channel == 0 ? q.lum_t : q.chr_t;
+        const float* rqt = channel == 0 ? q.rlum_t : q.rchr_t;
         int qv[64];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-#pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                float acc = cos_c(v, 0) * row[u][0];
-#pragma unroll
-                for (int y = 1; y < 8; ++y) acc += cos_c(v, y) * row[u][y];
-                const float o = scale_s(v) * acc;
-                const float quot = o / qt[8 * v + u];
-                qv[8 * v + u] = (int)floor(0.5 + (double)quot);
-            }
+            float o[8];
+            fdct_col(row, u, o);
+            quantise_col(o, qt, rqt, u, qv);
         }
-
         // zig-zag (entropy_encoder.cpp:15-77) and hand-over through LDS
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) {

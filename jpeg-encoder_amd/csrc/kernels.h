@@ -11,8 +11,14 @@ namespace jea {
 // Passed to kernels by value: it then lives in the kernarg segment, where
 // wave-uniform reads at compile-time offsets become scalar loads.
 struct QuantTables {
-    float lum[64];  // natural order, float(Q) as the reference converts it
-    float chr[64];  // (quantiser.cpp:61,66,76,81)
+    float lum[64];   // natural order, float(Q) as the reference converts it
+    float chr[64];   // (quantiser.cpp:61,66,76,81)
+    // Transposed copies ([u][v], i.e. index 8u+v holds entry 8v+u) in the order the
+    // forward kernel walks them, and their reciprocals RN(1/Q) for its fast path.
+    float lum_t[64];
+    float chr_t[64];
+    float rlum_t[64];
+    float rchr_t[64];
 };
 
 // Huffman code tables: entry = (length << 16) | code word, indexed by symbol.
