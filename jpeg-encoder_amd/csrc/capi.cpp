@@ -39,7 +39,7 @@ struct jea_ctx {
     DecodeTables* d_decode = nullptr;
     int32_t* d_status = nullptr;
     // scratch, grown on demand and kept
-    DeviceBuffer coefs, len16, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
+    DeviceBuffer coefs, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
     DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
 };
 
@@ -139,6 +139,8 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     const size_t nbc = mcus * 3, n_tiles = tiles_per_image(mcus);
     int rc;
     if ((rc = ensure(ctx, ctx->len16, n_images * nbc * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->slots, n_images * n_tiles * (size_t)kSlotWords * kSlotStride * sizeof(uint32_t))))
+        return rc;
     if ((rc = ensure(ctx, ctx->tile_bits, n_images * n_tiles * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->tile_base, n_images * n_tiles * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->tile_ff, n_images * n_tiles * sizeof(uint32_t)))) return rc;
@@ -149,6 +151,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     const size_t ucap = (out_capacity + 16 * n_images < worst) ? out_capacity + 16 * n_images : worst;
     if ((rc = ensure(ctx, ctx->unstuffed, ucap))) return rc;
     sc.len16 = (uint16_t*)ctx->len16.ptr;
+    sc.slots = (uint32_t*)ctx->slots.ptr;
     sc.tile_bits = (uint32_t*)ctx->tile_bits.ptr;
     sc.tile_base = (uint64_t*)ctx->tile_base.ptr;
     sc.tile_ff = (uint32_t*)ctx->tile_ff.ptr;
@@ -232,7 +235,7 @@ void jea_destroy(jea_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    for (DeviceBuffer* b : {&ctx->coefs, &ctx->len16, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
+    for (DeviceBuffer* b : {&ctx->coefs, &ctx->len16, &ctx->slots, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
                             &ctx->tile_ffbase, &ctx->img_words, &ctx->unstuffed, &ctx->stage_in, &ctx->stage_out,
                             &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes})
         free_buffer(*b);

@@ -6,15 +6,17 @@
 // semantics: a 0x00 after every 0xFF), zero-pads the last byte and appends EOI
 // (encoder.cpp:29-32).  Here the same byte string is produced in parallel:
 //
-//   bit_length_kernel   one thread per block-channel: run-length symbols and
-//                       total bit length (entropy_encoder.cpp:94-120, 715-765);
-//                       the DC difference needs only the previous MCU's DC of
-//                       the same channel, read straight from the coefficients
+//   block_bits_kernel   one thread per block-channel: run-length symbols, Huffman
+//                       codes and amplitude bits (entropy_encoder.cpp:94-120,
+//                       715-765) assembled MSB first into the block's own slot,
+//                       plus the block's bit length; the DC difference needs only
+//                       the previous MCU's DC of the same channel, read straight
+//                       from the coefficients
 //   scan_tiles_kernel   exclusive scan of the per-tile bit totals of each image
-//   pack_kernel         every tile regenerates its symbols, assembles them MSB
-//                       first in an LDS window at the scanned bit offset and
-//                       writes the bytes it owns of the not-yet-stuffed stream;
-//                       it also counts the 0xFF bytes among them
+//   pack_kernel         every tile shifts its blocks' bit strings to their
+//                       scanned bit offsets inside an LDS window and writes the
+//                       bytes it owns of the not-yet-stuffed stream; it also
+//                       counts the 0xFF bytes among them
 //   scan_tiles_kernel   exclusive scan of the per-tile 0xFF counts
 //   stuff_kernel        copies each tile's bytes to their final place,
 //                       inserting 0x00 after 0xFF; writes header and EOI
@@ -22,9 +24,13 @@
 // A tile is kTileBlocks = 252 consecutive block-channels (84 MCUs) of one image.
 // Byte ownership: a byte belongs to the tile that holds its first bit, so the
 // byte that straddles two tiles is produced by the earlier tile, which for that
-// purpose also encodes the first MCU of the next tile (3 block-channels are at
+// purpose also places the first MCU of the next tile (3 block-channels are at
 // least 14 bits, more than the 7 that can be missing).  No atomics on global
 // memory and no zero-filled output are needed.
+//
+// Slots: the bit string of block j of a tile lives in words slot[w][j],
+// w = 0..51 (1660 bits at most), of the tile's [52][256] word array, so that the
+// 256 threads of a workgroup touch consecutive addresses for equal w.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -118,39 +124,29 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
 struct CountSink {
     uint32_t bits = 0;
     __device__ __forceinline__ void put(uint32_t, uint32_t n) { bits += n; }
+    __device__ __forceinline__ void finish() {}
 };
 
-// MSB-first writer into the LDS window.  `word` is the tile-relative index of
-// the 32-bit word being filled, `nacc` how many of its leading bits are already
-// spoken for.  Words that lie wholly inside this block's bit range are stored
-// plainly; the first and the last word may be shared with neighbouring
-// block-channels and are OR-ed in.
-struct WindowSink {
-    uint32_t* win;
-    uint32_t word, wlo;
-    uint64_t acc;
-    uint32_t nacc;
-    bool first;
-    __device__ __forceinline__ void store(uint32_t v, bool shared_word) {
-        const uint32_t idx = word - wlo;
-        if (idx < kWinWords) {
-            if (shared_word) atomicOr(&win[idx], v);
-            else win[idx] = v;
-        }
-    }
-    __device__ __forceinline__ void put(uint32_t bits, uint32_t n) {
-        acc |= (uint64_t)bits << (64u - nacc - n);
+// MSB-first writer into the block's slot: full words go out as they complete,
+// the last partial word is zero padded.
+struct SlotSink {
+    uint32_t* slot;  // &tile_slots[0][j]; word w is slot[w * kSlotStride]
+    uint32_t bits = 0;
+    uint64_t acc = 0;
+    uint32_t nacc = 0;
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n) {
+        acc |= (uint64_t)v << (64u - nacc - n);
         nacc += n;
+        bits += n;
         if (nacc >= 32) {
-            store((uint32_t)(acc >> 32), first);
-            first = false;
+            *slot = (uint32_t)(acc >> 32);
+            slot += kSlotStride;
             acc <<= 32;
             nacc -= 32;
-            ++word;
         }
     }
     __device__ __forceinline__ void finish() {
-        if (nacc > 0) store((uint32_t)(acc >> 32), true);
+        if (nacc > 0) *slot = (uint32_t)(acc >> 32);
     }
 };
 
@@ -175,11 +171,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(kEntThreads) void bit_length_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+template <bool kEmit>
+__global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
                                                                  uint32_t n_tiles,
                                                                  const HuffTables* __restrict__ huff,
                                                                  uint16_t* __restrict__ len16,
                                                                  uint32_t* __restrict__ tile_bits,
+                                                                 uint32_t* __restrict__ slots,
                                                                  int32_t* __restrict__ status) {
     __shared__ HuffLds h;
     __shared__ uint32_t wsum[4];
@@ -194,10 +192,19 @@ __global__ __launch_bounds__(kEntThreads) void bit_length_kernel(const int16_t* 
         load_block(blk, p);
         const int ch = (int)(b % 3u);
         const int prev_dc = (b >= 3) ? (int)p[-192] : 0;  // same channel, previous MCU (encoder.cpp:20)
-        CountSink sink;
-        const bool ok = encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
+        bool ok;
+        if (kEmit) {
+            SlotSink sink;
+            sink.slot = slots + ((size_t)img * n_tiles + tile) * kSlotWords * kSlotStride + threadIdx.x;
+            ok = encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
+            sink.finish();
+            bits = sink.bits;
+        } else {
+            CountSink sink;
+            ok = encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
+            bits = sink.bits;
+        }
         if (!ok) atomicExch(status, JEA_ERR_RANGE);
-        bits = sink.bits;
         len16[(size_t)img * nbc + b] = (uint16_t)bits;
     }
     uint32_t total;
@@ -319,8 +326,8 @@ __device__ __forceinline__ void tile_owned_bytes(uint32_t tile, uint32_t n_tiles
     b1 = (end_bits + 7) >> 3;
 }
 
-__global__ __launch_bounds__(kEntThreads) void pack_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
-                                                           uint32_t n_tiles, const HuffTables* __restrict__ huff,
+__global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_t n_tiles,
+                                                           const uint32_t* __restrict__ slots,
                                                            const uint16_t* __restrict__ len16,
                                                            const uint64_t* __restrict__ tile_base,
                                                            const uint64_t* __restrict__ img_bits,
@@ -328,12 +335,10 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(const int16_t* __rest
                                                            uint8_t* __restrict__ unstuffed,
                                                            uint32_t* __restrict__ tile_ff,
                                                            const int32_t* __restrict__ status) {
-    __shared__ HuffLds h;
-    __shared__ uint32_t win[kWinWords];
+    __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t ff_count;
     if (*status != 0) return;
-    load_huff(h, huff);
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     // 252 own block-channels + the first MCU of the next tile (threads 252..254)
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(const int16_t* __rest
     const uint32_t my_len = has_block ? len16[(size_t)img * nbc + b] : 0;
     if (threadIdx.x == 0) ff_count = 0;
     uint32_t tile_total;
-    const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);  // has barriers: h, ff_count ready
+    const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);  // has barriers
 
     uint64_t base_bits, b0, b1;
     tile_owned_bytes(tile, n_tiles, tile_base + (size_t)img * n_tiles, img_bits[img], base_bits, b0, b1);
@@ -350,29 +355,29 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(const int16_t* __rest
     const uint32_t n_words = (uint32_t)((b1 * 8 - d0 * 32 + 31) >> 5);  // words that hold owned bytes
     uint8_t* dst = unstuffed + img_ubase[img];
 
-    BlockRegs blk;
-    int prev_dc = 0;
-    const int ch = (int)(b % 3u);
-    if (has_block) {
-        const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
-        load_block(blk, p);
-        prev_dc = (b >= 3) ? (int)p[-192] : 0;
-    }
+    // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
+    const uint32_t slot_tile = threadIdx.x < kTileBlocks ? tile : tile + 1;
+    const uint32_t slot_col = threadIdx.x < kTileBlocks ? threadIdx.x : threadIdx.x - kTileBlocks;
+    const uint32_t* slot = slots + ((size_t)img * n_tiles + slot_tile) * kSlotWords * kSlotStride + slot_col;
+    const uint32_t my_words = (my_len + 31) >> 5;
+    const uint32_t sh = rel_start & 31u;
 
     uint32_t my_ff = 0;
     for (uint32_t wlo = 0; wlo < n_words; wlo += kWinWords) {
-        for (uint32_t i = threadIdx.x; i < kWinWords; i += kEntThreads) win[i] = 0;
+        const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
+        for (uint32_t i = threadIdx.x; i < words_here + 2; i += kEntThreads) win[i] = 0;
         __syncthreads();
-        if (has_block) {
-            const uint32_t first_word = rel_start >> 5, last_word = (rel_start + my_len - 1) >> 5;
-            if (last_word >= wlo && first_word < wlo + kWinWords) {
-                WindowSink sink{win, first_word, wlo, 0, rel_start & 31u, true};
-                (void)encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
-                sink.finish();
+        // word w of the block's string covers stream words first+w and first+w+1
+        const uint32_t first = rel_start >> 5;
+        for (uint32_t w = 0; w < my_words; ++w) {
+            const uint32_t idx = first + w - wlo;        // wraps below the window: rejected by the range test
+            if (idx + 1 < kWinWords + 1 || idx == 0xffffffffu) {
+                const uint32_t v = slot[(size_t)w * kSlotStride];
+                if (idx < kWinWords) atomicOr(&win[idx], v >> sh);
+                if (sh != 0 && idx + 1 < kWinWords) atomicOr(&win[idx + 1], v << (32u - sh));
             }
         }
         __syncthreads();
-        const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
         for (uint32_t i = threadIdx.x; i < words_here; i += kEntThreads) {
             const uint32_t v = win[i];
             const uint64_t byte0 = (d0 + wlo + i) * 4;  // image-relative index of the word's first byte
@@ -628,8 +633,8 @@ void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, 
                         const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status) {
     const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
-    bit_length_kernel<<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, d_len16,
-                                                                               d_tile_bits, d_status);
+    block_bits_kernel<false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
+        d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status);
 }
 
 void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -641,13 +646,14 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const dim3 grid(n_tiles, (unsigned)n_images);
     const uint32_t n = (uint32_t)n_images;
 
-    bit_length_kernel<<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits, d_status);
+    block_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
+                                                         sc.slots, d_status);
 
     ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
     scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
     if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_bits, l1);
 
-    pack_kernel<<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_base, sc.img_bits,
+    pack_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_base, sc.img_bits,
                                              sc.img_ubase, sc.unstuffed, sc.tile_ff, d_status);
 
     ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity,

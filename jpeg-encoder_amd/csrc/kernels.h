@@ -48,6 +48,10 @@ struct HeaderBytes {
 // Entropy coding works on tiles of kTileBlocks consecutive block-channels of
 // one image (84 MCUs); tiles never straddle images.
 constexpr int kTileBlocks = 252;
+// Bit string of one block-channel: at most 22 + 63 * 26 = 1660 bits = 52 words.
+// A tile's slots are a [kSlotWords][kSlotStride] word array, block j in column j.
+constexpr int kSlotWords = 52;
+constexpr int kSlotStride = 256;
 
 inline uint32_t tiles_per_image(size_t mcus_per_image) {
     return (uint32_t)((mcus_per_image * 3 + kTileBlocks - 1) / kTileBlocks);
@@ -57,6 +61,7 @@ inline uint32_t tiles_per_image(size_t mcus_per_image) {
 // scratch.  n_tiles = tiles per image, n = images.
 struct EntropyScratch {
     uint16_t* len16;        // [n][mcus*3]      bits per block-channel
+    uint32_t* slots;        // [n][n_tiles][kSlotWords][kSlotStride]  per-block bit strings
     uint32_t* tile_bits;    // [n][n_tiles]
     uint64_t* tile_base;    // [n][n_tiles]     exclusive scan of tile_bits within the image
     uint32_t* tile_ff;      // [n][n_tiles]     0xFF bytes among the tile's owned bytes
