@@ -392,7 +392,7 @@ int jea_fdct_quant_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, ui
         !tables_ok(lum_q, chr_q))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_fdct_quant: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
-    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs);
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, nullptr);
     JEA_HIP(ctx, hipGetLastError());
     return JEA_OK;
 }
@@ -455,11 +455,12 @@ int jea_block_bit_lengths(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images,
 
 static int entropy_encode_common(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus,
                                  const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
-                                 size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
+                                 size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status,
+                                 bool status_is_clear) {
     EntropyScratch sc;
     int rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc);
     if (rc) return rc;
-    JEA_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t), ctx->stream));
+    if (!status_is_clear) JEA_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t), ctx->stream));
     launch_entropy_encode(ctx->stream, d_coefs, n_images, mcus, ctx->d_huff, sc, header, header_len, with_eoi, d_out,
                           out_capacity, d_offsets, d_sizes, d_status);
     JEA_HIP(ctx, hipGetLastError());
@@ -485,7 +486,7 @@ int jea_entropy_encode(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, si
     if ((rc = ensure(ctx, ctx->out_sizes, n_images * sizeof(uint64_t)))) return rc;
     HeaderBytes hb{};
     rc = entropy_encode_common(ctx, d_coefs, n_images, mcus_per_image, hb, 0, false, d_out, out_capacity,
-                               (uint64_t*)ctx->out_offsets.ptr, (uint64_t*)ctx->out_sizes.ptr, ctx->d_status);
+                               (uint64_t*)ctx->out_offsets.ptr, (uint64_t*)ctx->out_sizes.ptr, ctx->d_status, false);
     if (rc) return rc;
     if ((rc = fetch_offsets_sizes(ctx, n_images, (uint64_t*)ctx->out_offsets.ptr, (uint64_t*)ctx->out_sizes.ptr,
                                   h_offsets, h_sizes)))
@@ -507,12 +508,15 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
     int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
+    // scratch first: growing a buffer synchronises the stream, which must not happen between the launches
+    EntropyScratch sc;
+    if ((rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc))) return rc;
     HeaderBytes hb{};
     jea_write_header(hb.b, width, height, lum_q, chr_q);
-    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs);
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status);
     JEA_HIP(ctx, hipGetLastError());
     return entropy_encode_common(ctx, d_coefs, n_images, mcus, hb, JEA_HEADER_BYTES, true, d_out, out_capacity,
-                                 d_offsets, d_sizes, d_status);
+                                 d_offsets, d_sizes, d_status, true);
 }
 
 int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,

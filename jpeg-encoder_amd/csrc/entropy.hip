@@ -43,6 +43,7 @@ namespace {
 
 constexpr int kEntThreads = 256;
 constexpr uint32_t kWinWords = 4096;  // 16 KiB LDS window of the packed stream
+constexpr uint32_t kFoldTiles = 4096;  // single images up to this many tiles skip the scan launches
 
 struct HuffLds {
     uint32_t dc[2][12];
@@ -94,24 +95,36 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
         sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
     }
     uint32_t run = 0;
+    // Coefficients are walked in groups of eight (one 16-byte load); a group that is
+    // all zero only extends the run.  High zig-zag positions are zero in most
+    // blocks, and a wave skips the group body when none of its lanes needs it.
 #pragma unroll
-    for (int k = 1; k < 64; ++k) {
-        const int v = blk.at(k);
-        if (v != 0) {
-            while (run >= 16) {
-                const uint32_t z = ac_tab[0xF0];
-                sink.put(z & 0xffffu, z >> 16);
-                run -= 16;
+    for (int g = 0; g < 8; ++g) {
+        const uint32_t any = (g == 0 ? (blk.w[0] & 0xffff0000u) : blk.w[4 * g]) | blk.w[4 * g + 1] | blk.w[4 * g + 2] |
+                             blk.w[4 * g + 3];
+        if (any == 0) {
+            run += (g == 0) ? 7u : 8u;
+            continue;
+        }
+#pragma unroll
+        for (int k = (g == 0 ? 1 : 8 * g); k < 8 * g + 8; ++k) {
+            const int v = blk.at(k);
+            if (v != 0) {
+                while (run >= 16) {
+                    const uint32_t z = ac_tab[0xF0];
+                    sink.put(z & 0xffffu, z >> 16);
+                    run -= 16;
+                }
+                const uint32_t amp = (uint32_t)(v < 0 ? -v : v);
+                uint32_t s = bit_width(amp);
+                if (s > 10) { ok = false; s = 10; }
+                const uint32_t e = ac_tab[(run << 4) | s];
+                const uint32_t extra = (v > 0 ? amp : ~amp) & ((1u << s) - 1u);
+                sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
+                run = 0;
+            } else {
+                ++run;
             }
-            const uint32_t amp = (uint32_t)(v < 0 ? -v : v);
-            uint32_t s = bit_width(amp);
-            if (s > 10) { ok = false; s = 10; }
-            const uint32_t e = ac_tab[(run << 4) | s];
-            const uint32_t extra = (v > 0 ? amp : ~amp) & ((1u << s) - 1u);
-            sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
-            run = 0;
-        } else {
-            ++run;
         }
     }
     if (run > 0) {  // zz[63] == 0: trailing zeros (and their ZRLs) collapse into EOB
@@ -317,26 +330,53 @@ __global__ __launch_bounds__(1024) void scan_images_kernel(uint32_t n_images, co
     }
 }
 
-// Owned byte range [b0, b1) of a tile inside its image's unstuffed stream.
-__device__ __forceinline__ void tile_owned_bytes(uint32_t tile, uint32_t n_tiles, const uint64_t* __restrict__ tb,
-                                                 uint64_t img_bits, uint64_t& base_bits, uint64_t& b0, uint64_t& b1) {
-    base_bits = tb[tile];
-    const uint64_t end_bits = (tile + 1 == n_tiles) ? img_bits : tb[tile + 1];
-    b0 = (base_bits + 7) >> 3;
-    b1 = (end_bits + 7) >> 3;
+// Sum of arr[0..count) over a 256-thread workgroup (every thread gets the result).
+// Used instead of a separate scan launch when one image has few tiles: each
+// workgroup adds up the totals of the tiles before it.
+__device__ __forceinline__ uint64_t block_sum_256(const uint32_t* __restrict__ arr, uint32_t count, uint64_t* lds4) {
+    uint64_t v = 0;
+    for (uint32_t i = threadIdx.x; i < count; i += kEntThreads) v += arr[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint64_t total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return total;
 }
 
+// Bit range [base_bits, end_bits) of a tile in its image's stream: from the
+// scanned tile bases, or (kFold, single image) by summing the tile totals.
+template <bool kFold>
+__device__ __forceinline__ void tile_bit_range(uint32_t tile, uint32_t n_tiles, const uint32_t* __restrict__ tile_bits,
+                                               const uint64_t* __restrict__ tile_base,
+                                               const uint64_t* __restrict__ img_bits, uint32_t img, uint64_t* lds4,
+                                               uint64_t& base_bits, uint64_t& end_bits) {
+    if (kFold) {
+        base_bits = block_sum_256(tile_bits, tile, lds4);
+        end_bits = base_bits + tile_bits[tile];
+    } else {
+        const uint64_t* tb = tile_base + (size_t)img * n_tiles;
+        base_bits = tb[tile];
+        end_bits = (tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1];
+    }
+}
+
+template <bool kFold>
 __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_t n_tiles,
                                                            const uint32_t* __restrict__ slots,
                                                            const uint16_t* __restrict__ len16,
+                                                           const uint32_t* __restrict__ tile_bits,
                                                            const uint64_t* __restrict__ tile_base,
                                                            const uint64_t* __restrict__ img_bits,
                                                            const uint64_t* __restrict__ img_ubase,
                                                            uint8_t* __restrict__ unstuffed,
+                                                           uint64_t unstuffed_capacity,
                                                            uint32_t* __restrict__ tile_ff,
-                                                           const int32_t* __restrict__ status) {
+                                                           int32_t* __restrict__ status) {
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4];
+    __shared__ uint64_t lsum[4];
     __shared__ uint32_t ff_count;
     if (*status != 0) return;
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
@@ -348,12 +388,18 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     uint32_t tile_total;
     const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);  // has barriers
 
-    uint64_t base_bits, b0, b1;
-    tile_owned_bytes(tile, n_tiles, tile_base + (size_t)img * n_tiles, img_bits[img], base_bits, b0, b1);
+    uint64_t base_bits, end_bits;
+    tile_bit_range<kFold>(tile, n_tiles, tile_bits, tile_base, img_bits, img, lsum, base_bits, end_bits);
+    const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1)
     const uint64_t d0 = base_bits >> 5;                      // image-relative dword of window word 0
     const uint32_t rel_start = (uint32_t)(base_bits & 31) + local_off;
     const uint32_t n_words = (uint32_t)((b1 * 8 - d0 * 32 + 31) >> 5);  // words that hold owned bytes
-    uint8_t* dst = unstuffed + img_ubase[img];
+    const uint64_t ubase = kFold ? 0 : img_ubase[img];
+    if (kFold && ((b1 + 3) & ~3ull) > unstuffed_capacity) {  // single image: no scan kernel has checked this
+        if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
+        return;
+    }
+    uint8_t* dst = unstuffed + ubase;
 
     // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
     const uint32_t slot_tile = threadIdx.x < kTileBlocks ? tile : tile + 1;
@@ -404,29 +450,54 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     if (threadIdx.x == 0) tile_ff[(size_t)img * n_tiles + tile] = ff_count;
 }
 
-__global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, const uint64_t* __restrict__ tile_base,
+template <bool kFold>
+__global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, const uint32_t* __restrict__ tile_bits,
+                                                            const uint64_t* __restrict__ tile_base,
                                                             const uint64_t* __restrict__ img_bits,
                                                             const uint64_t* __restrict__ img_ubase,
                                                             const uint8_t* __restrict__ unstuffed,
+                                                            const uint32_t* __restrict__ tile_ff,
                                                             const uint64_t* __restrict__ tile_ffbase,
                                                             const uint64_t* __restrict__ img_ff,
-                                                            const uint64_t* __restrict__ offsets, HeaderBytes header,
+                                                            uint64_t* __restrict__ offsets,
+                                                            uint64_t* __restrict__ sizes, HeaderBytes header,
                                                             uint32_t header_len, uint32_t with_eoi,
-                                                            uint8_t* __restrict__ out,
-                                                            const int32_t* __restrict__ status) {
+                                                            uint8_t* __restrict__ out, uint64_t out_capacity,
+                                                            int32_t* __restrict__ status) {
     __shared__ uint32_t wsum[4];
+    __shared__ uint64_t lsum[4];
     if (*status != 0) return;
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
-    uint64_t base_bits, b0, b1;
-    tile_owned_bytes(tile, n_tiles, tile_base + (size_t)img * n_tiles, img_bits[img], base_bits, b0, b1);
-    const uint8_t* src = unstuffed + img_ubase[img];
-    uint8_t* file = out + offsets[img];
-    uint8_t* dst = file + header_len + tile_ffbase[(size_t)img * n_tiles + tile];  // + source index + 0xFFs before it
+    uint64_t base_bits, end_bits;
+    tile_bit_range<kFold>(tile, n_tiles, tile_bits, tile_base, img_bits, img, lsum, base_bits, end_bits);
+    const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;
+    uint64_t ff_before, file_offset;
+    if (kFold) {
+        ff_before = block_sum_256(tile_ff, tile, lsum);
+        file_offset = 0;
+        // the tile's last output byte (and, for the last tile, the EOI) must fit
+        const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
+        if (header_len + b1 + ff_before + tile_ff[tile] + tail > out_capacity) {
+            if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
+            return;
+        }
+        if (tile + 1 == n_tiles && threadIdx.x == 0) {
+            offsets[0] = 0;
+            sizes[0] = header_len + b1 + ff_before + tile_ff[tile] + tail;
+        }
+    } else {
+        ff_before = tile_ffbase[(size_t)img * n_tiles + tile];
+        file_offset = offsets[img];
+    }
+    const uint8_t* src = unstuffed + (kFold ? 0 : img_ubase[img]);
+    uint8_t* file = out + file_offset;
+    uint8_t* dst = file + header_len + ff_before;  // + source index + 0xFFs before it inside the tile
 
     if (tile == 0)
         for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) file[i] = header.b[i];
     if (tile + 1 == n_tiles && with_eoi && threadIdx.x == 0) {
-        uint8_t* e = file + header_len + b1 + img_ff[img];
+        const uint64_t ff_total = kFold ? ff_before + tile_ff[tile] : img_ff[img];
+        uint8_t* e = file + header_len + b1 + ff_total;
         e[0] = 0xFF;
         e[1] = 0xD9;
     }
@@ -645,25 +716,39 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
     const dim3 grid(n_tiles, (unsigned)n_images);
     const uint32_t n = (uint32_t)n_images;
+    const uint32_t eoi = with_eoi ? 1u : 0u;
 
     block_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
                                                          sc.slots, d_status);
+
+    if (n == 1 && n_tiles <= kFoldTiles) {
+        // One image with few tiles: every workgroup sums the totals of the tiles
+        // before it, which is cheaper than two dependent single-workgroup scans.
+        pack_kernel<true><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, nullptr, nullptr,
+                                                       nullptr, sc.unstuffed, sc.unstuffed_capacity, sc.tile_ff,
+                                                       d_status);
+        stuff_kernel<true><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, nullptr, nullptr, nullptr, sc.unstuffed,
+                                                        sc.tile_ff, nullptr, nullptr, d_offsets, d_sizes, header,
+                                                        (uint32_t)header_len, eoi, d_out, out_capacity, d_status);
+        return;
+    }
 
     ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
     scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
     if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_bits, l1);
 
-    pack_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_base, sc.img_bits,
-                                             sc.img_ubase, sc.unstuffed, sc.tile_ff, d_status);
+    pack_kernel<false><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
+                                                    sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
+                                                    sc.tile_ff, d_status);
 
-    ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity,
-                  (uint32_t)header_len + (with_eoi ? 2u : 0u), d_status};
+    ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
     scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
     if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, l2);
 
-    stuff_kernel<<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_base, sc.img_bits, sc.img_ubase, sc.unstuffed,
-                                              sc.tile_ffbase, sc.img_ff, d_offsets, header, (uint32_t)header_len,
-                                              with_eoi ? 1u : 0u, d_out, d_status);
+    stuff_kernel<false><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
+                                                     sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets,
+                                                     d_sizes, header, (uint32_t)header_len, eoi, d_out, out_capacity,
+                                                     d_status);
 }
 
 void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,

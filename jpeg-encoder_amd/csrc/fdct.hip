@@ -138,7 +138,11 @@ template <bool kFast>
 __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t* __restrict__ rgb, int width,
                                                                   int height, int blocks_w, uint32_t n_mcu,
                                                                   size_t image_bytes, QuantTables q,
-                                                                  int16_t* __restrict__ coefs) {
+                                                                  int16_t* __restrict__ coefs,
+                                                                  int32_t* __restrict__ status_to_clear) {
+    // First kernel of an encode pass: clears the pass's status word so that no
+    // separate memset launch is needed (later kernels only ever raise it).
+    if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status_to_clear = 0;
     // One buffer, used twice: first the pixel rows of the 64 MCUs
     // ([row 0..7][mcu 0..63][8 px * 3 B], 12 KiB), then, after every wave has
     // finished its row pass, the finished blocks ([mcu][channel][128 B] with the
@@ -378,16 +382,18 @@ __global__ void ycbcr_to_rgb_kernel(const uint8_t* __restrict__ ycc, size_t n, u
 }  // namespace
 
 void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
-                       const QuantTables& q, int16_t* d_coefs) {
+                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
     const bool fast = (width % 8 == 0) && ((reinterpret_cast<uintptr_t>(d_rgb) & 7u) == 0);
     if (fast)
-        fdct_quant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs);
+        fdct_quant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+                                                              d_status_to_clear);
     else
-        fdct_quant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs);
+        fdct_quant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+                                                               d_status_to_clear);
 }
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,

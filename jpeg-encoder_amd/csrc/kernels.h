@@ -73,8 +73,9 @@ struct EntropyScratch {
     size_t unstuffed_capacity;
 };
 
+// d_status_to_clear (may be null): status word of the encode pass this launch opens; the kernel zeroes it.
 void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
-                       const QuantTables& q, int16_t* d_coefs);
+                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear);
 
 void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
                         const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status);
