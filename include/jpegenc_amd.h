@@ -174,6 +174,44 @@ int jea_idct_dequant(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, uint
 int jea_rgb_to_ycbcr(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc);
 int jea_ycbcr_to_rgb(jea_ctx* ctx, const uint8_t* d_ycc, size_t n_pixels, uint8_t* d_rgb);
 
+/* ---- component-level entry points (host pointers, synchronous) ---------
+ * The granularity of the reference's injected components: one 8x8 block-channel
+ * (or pixel block) per element.  They run the same device code as the image
+ * kernels; they are meant for the per-block methods of the host classes and for
+ * tests, not for throughput. */
+
+/* ColourMapper::map / unmap on n pixels (colour_mapping.cpp:44-67, :69-92). */
+int jea_rgb_to_ycbcr_host(jea_ctx* ctx, const uint8_t* h_rgb, size_t n_pixels, uint8_t* h_ycc);
+int jea_ycbcr_to_rgb_host(jea_ctx* ctx, const uint8_t* h_ycc, size_t n_pixels, uint8_t* h_rgb);
+
+/* DiscreteCosineTransformer::transform / inverseTransform with the separated
+ * transform (discrete_cosine_transform.cpp:3-27, 77-156): n blocks of 64 u8
+ * samples (index x + 8y) <-> 64 floats (index u + 8v). */
+int jea_dct_forward_blocks(jea_ctx* ctx, const uint8_t* h_samples, size_t n_blocks, float* h_dct);
+int jea_dct_inverse_blocks(jea_ctx* ctx, const float* h_dct, size_t n_blocks, uint8_t* h_samples);
+
+/* Quantiser::quantise / dequantise (quantiser.cpp:57-85) with one table, natural order. */
+int jea_quantise_blocks(jea_ctx* ctx, const float* h_dct, size_t n_blocks, const uint16_t table[64],
+                        int16_t* h_quantised);
+int jea_dequantise_blocks(jea_ctx* ctx, const int16_t* h_quantised, size_t n_blocks, const uint16_t table[64],
+                          float* h_dct);
+
+/* HuffmanEncoder encode of independent block-channels (entropy_encoder.cpp:94-120,
+ * 696-765): zig-zag ordered coefficients, the previous DC value and the table
+ * class (non-zero = luminance) per block.  h_lengths[i] receives the bit count,
+ * h_bits[i*52 .. i*52+51] the bits, MSB first in each 32-bit word, zero padded. */
+int jea_huffman_encode_blocks(jea_ctx* ctx, const int16_t* h_zigzag, const int16_t* h_prev_dc,
+                              const uint8_t* h_is_luminance, size_t n_blocks, uint16_t* h_lengths, uint32_t* h_bits);
+
+/* HuffmanEncoder decode of one block-channel (entropy_encoder.cpp:122-144, 703-712,
+ * 767-866) from an unstuffed stream.  jea_stream_upload copies the stream to the
+ * GPU once; jea_huffman_decode_block then decodes the block that starts at
+ * `start_bit`, returns its zig-zag coefficients (with the reference's dropped
+ * last run-length entry), the bit position after it and the updated DC value. */
+int jea_stream_upload(jea_ctx* ctx, const uint8_t* h_stream, size_t len);
+int jea_huffman_decode_block(jea_ctx* ctx, uint64_t start_bit, int is_luminance, int16_t* last_dc,
+                             int16_t h_zigzag[64], uint64_t* end_bit);
+
 /* ---- device memory helpers for callers without a HIP binding ---------- */
 int jea_malloc(jea_ctx* ctx, size_t bytes, void** d_ptr);
 int jea_free(jea_ctx* ctx, void* d_ptr);

@@ -18,6 +18,9 @@ EXPORTS = [
     "jea_decode_batch", "jea_decode_host",
     "jea_fdct_quant", "jea_fdct_quant_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
     "jea_rgb_to_ycbcr", "jea_ycbcr_to_rgb",
+    "jea_rgb_to_ycbcr_host", "jea_ycbcr_to_rgb_host", "jea_dct_forward_blocks", "jea_dct_inverse_blocks",
+    "jea_quantise_blocks", "jea_dequantise_blocks", "jea_huffman_encode_blocks", "jea_stream_upload",
+    "jea_huffman_decode_block",
     "jea_malloc", "jea_free", "jea_memcpy_h2d", "jea_memcpy_d2h",
 ]
 
@@ -71,6 +74,15 @@ def load_library():
     lib.jea_idct_dequant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_rgb_to_ycbcr.argtypes = [vp, vp, sz, vp]
     lib.jea_ycbcr_to_rgb.argtypes = [vp, vp, sz, vp]
+    lib.jea_rgb_to_ycbcr_host.argtypes = [vp, vp, sz, vp]
+    lib.jea_ycbcr_to_rgb_host.argtypes = [vp, vp, sz, vp]
+    lib.jea_dct_forward_blocks.argtypes = [vp, vp, sz, vp]
+    lib.jea_dct_inverse_blocks.argtypes = [vp, vp, sz, vp]
+    lib.jea_quantise_blocks.argtypes = [vp, vp, sz, vp, vp]
+    lib.jea_dequantise_blocks.argtypes = [vp, vp, sz, vp, vp]
+    lib.jea_huffman_encode_blocks.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.jea_stream_upload.argtypes = [vp, vp, sz]
+    lib.jea_huffman_decode_block.argtypes = [vp, c.c_uint64, i32, c.POINTER(c.c_int16), vp, c.POINTER(c.c_uint64)]
     lib.jea_malloc.argtypes = [vp, sz, c.POINTER(vp)]
     lib.jea_free.argtypes = [vp, vp]
     lib.jea_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -210,6 +222,55 @@ class Context:
         self.torch.cuda.synchronize(self.tdev)
         self._check(self.lib.jea_ycbcr_to_rgb(self.handle, d_ycc.data_ptr(), d_ycc.numel() // 3, out.data_ptr()))
         return out
+
+    # ---- component level (host arrays) ----
+    def dct_forward_blocks(self, samples):
+        a = np.ascontiguousarray(samples, np.uint8).reshape(-1, 64)
+        out = np.zeros(a.shape, np.float32)
+        self._check(self.lib.jea_dct_forward_blocks(self.handle, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
+
+    def dct_inverse_blocks(self, dct):
+        a = np.ascontiguousarray(dct, np.float32).reshape(-1, 64)
+        out = np.zeros(a.shape, np.uint8)
+        self._check(self.lib.jea_dct_inverse_blocks(self.handle, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
+
+    def quantise_blocks(self, dct, table):
+        a = np.ascontiguousarray(dct, np.float32).reshape(-1, 64)
+        out = np.zeros(a.shape, np.int16)
+        self._check(self.lib.jea_quantise_blocks(self.handle, a.ctypes.data, a.shape[0], table.ctypes.data,
+                                                 out.ctypes.data))
+        return out
+
+    def dequantise_blocks(self, q, table):
+        a = np.ascontiguousarray(q, np.int16).reshape(-1, 64)
+        out = np.zeros(a.shape, np.float32)
+        self._check(self.lib.jea_dequantise_blocks(self.handle, a.ctypes.data, a.shape[0], table.ctypes.data,
+                                                   out.ctypes.data))
+        return out
+
+    def huffman_encode_blocks(self, zigzag, prev_dc, is_lum):
+        a = np.ascontiguousarray(zigzag, np.int16).reshape(-1, 64)
+        dc = np.ascontiguousarray(prev_dc, np.int16)
+        cls = np.ascontiguousarray(is_lum, np.uint8)
+        lengths = np.zeros(a.shape[0], np.uint16)
+        bits = np.zeros((a.shape[0], 52), np.uint32)
+        self._check(self.lib.jea_huffman_encode_blocks(self.handle, a.ctypes.data, dc.ctypes.data, cls.ctypes.data,
+                                                       a.shape[0], lengths.ctypes.data, bits.ctypes.data))
+        return lengths, bits
+
+    def stream_upload(self, stream):
+        buf = np.frombuffer(stream, np.uint8)
+        self._check(self.lib.jea_stream_upload(self.handle, buf.ctypes.data, buf.size))
+
+    def huffman_decode_block(self, start_bit, is_lum, last_dc):
+        dc = ctypes.c_int16(last_dc)
+        zz = np.zeros(64, np.int16)
+        end = ctypes.c_uint64(0)
+        self._check(self.lib.jea_huffman_decode_block(self.handle, start_bit, int(is_lum), ctypes.byref(dc),
+                                                      zz.ctypes.data, ctypes.byref(end)))
+        return zz, end.value, dc.value
 
     # ---- whole path ----
     def encode_batch(self, d_rgb, n_images, w, h, lum, chrom, capacity=None, d_out=None):

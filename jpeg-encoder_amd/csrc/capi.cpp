@@ -41,6 +41,8 @@ struct jea_ctx {
     // scratch, grown on demand and kept
     DeviceBuffer coefs, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
     DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
+    DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
+    size_t stream_len = 0;
 };
 
 namespace {
@@ -187,6 +189,32 @@ struct HeaderCheck {
 
 }  // namespace
 
+namespace {
+
+// host -> device staging, kernel, device -> host; `in_bytes` / `out_bytes` per call
+template <class Launch>
+int staged_call(jea_ctx* ctx, const void* h_in, size_t in_bytes, void* h_out, size_t out_bytes, Launch&& launch) {
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stage_in, in_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, out_bytes))) return rc;
+    JEA_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, h_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch(ctx->stage_in.ptr, ctx->stage_out.ptr);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipMemcpyAsync(h_out, ctx->stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+bool table_ok(const uint16_t t[64]) {
+    if (!t) return false;
+    for (int i = 0; i < 64; ++i)
+        if (t[i] == 0) return false;
+    return true;
+}
+
+}  // namespace
+
 extern "C" {
 
 int jea_create(int device_id, jea_ctx** out_ctx) {
@@ -237,7 +265,7 @@ void jea_destroy(jea_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (DeviceBuffer* b : {&ctx->coefs, &ctx->len16, &ctx->slots, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
                             &ctx->tile_ffbase, &ctx->img_words, &ctx->unstuffed, &ctx->stage_in, &ctx->stage_out,
-                            &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes})
+                            &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small})
         free_buffer(*b);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_decode) (void)hipFree(ctx->d_decode);
@@ -653,6 +681,128 @@ int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t wi
     if (rc) return rc;
     JEA_HIP(ctx, hipMemcpyAsync(h_rgb, ctx->stage_in.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JEA_OK;
+}
+
+// ---- component-level entry points ---------------------------------------------
+
+int jea_rgb_to_ycbcr_host(jea_ctx* ctx, const uint8_t* h_rgb, size_t n_pixels, uint8_t* h_ycc) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_rgb || !h_ycc || n_pixels == 0) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_rgb_to_ycbcr_host: invalid argument");
+    return staged_call(ctx, h_rgb, 3 * n_pixels, h_ycc, 3 * n_pixels, [&](void* in, void* out) {
+        launch_rgb_to_ycbcr(ctx->stream, (const uint8_t*)in, n_pixels, (uint8_t*)out);
+    });
+}
+
+int jea_ycbcr_to_rgb_host(jea_ctx* ctx, const uint8_t* h_ycc, size_t n_pixels, uint8_t* h_rgb) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_rgb || !h_ycc || n_pixels == 0) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_ycbcr_to_rgb_host: invalid argument");
+    return staged_call(ctx, h_ycc, 3 * n_pixels, h_rgb, 3 * n_pixels, [&](void* in, void* out) {
+        launch_ycbcr_to_rgb(ctx->stream, (const uint8_t*)in, n_pixels, (uint8_t*)out);
+    });
+}
+
+int jea_dct_forward_blocks(jea_ctx* ctx, const uint8_t* h_samples, size_t n_blocks, float* h_dct) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_samples || !h_dct || n_blocks == 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_dct_forward_blocks: invalid argument");
+    return staged_call(ctx, h_samples, 64 * n_blocks, h_dct, 256 * n_blocks, [&](void* in, void* out) {
+        launch_dct_forward_blocks(ctx->stream, (const uint8_t*)in, n_blocks, (float*)out);
+    });
+}
+
+int jea_dct_inverse_blocks(jea_ctx* ctx, const float* h_dct, size_t n_blocks, uint8_t* h_samples) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_samples || !h_dct || n_blocks == 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_dct_inverse_blocks: invalid argument");
+    return staged_call(ctx, h_dct, 256 * n_blocks, h_samples, 64 * n_blocks, [&](void* in, void* out) {
+        launch_dct_inverse_blocks(ctx->stream, (const float*)in, n_blocks, (uint8_t*)out);
+    });
+}
+
+int jea_quantise_blocks(jea_ctx* ctx, const float* h_dct, size_t n_blocks, const uint16_t table[64],
+                        int16_t* h_quantised) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_dct || !h_quantised || n_blocks == 0 || !table_ok(table))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_quantise_blocks: invalid argument");
+    const QuantTables q = to_float_tables(table, table);
+    return staged_call(ctx, h_dct, 256 * n_blocks, h_quantised, 128 * n_blocks, [&](void* in, void* out) {
+        launch_quantise_blocks(ctx->stream, (const float*)in, n_blocks, q, true, (int16_t*)out);
+    });
+}
+
+int jea_dequantise_blocks(jea_ctx* ctx, const int16_t* h_quantised, size_t n_blocks, const uint16_t table[64],
+                          float* h_dct) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_dct || !h_quantised || n_blocks == 0 || !table_ok(table))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_dequantise_blocks: invalid argument");
+    const QuantTables q = to_float_tables(table, table);
+    return staged_call(ctx, h_quantised, 128 * n_blocks, h_dct, 256 * n_blocks, [&](void* in, void* out) {
+        launch_dequantise_blocks(ctx->stream, (const int16_t*)in, n_blocks, q, true, (float*)out);
+    });
+}
+
+int jea_huffman_encode_blocks(jea_ctx* ctx, const int16_t* h_zigzag, const int16_t* h_prev_dc,
+                              const uint8_t* h_is_luminance, size_t n_blocks, uint16_t* h_lengths, uint32_t* h_bits) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_zigzag || !h_prev_dc || !h_is_luminance || !h_lengths || !h_bits || n_blocks == 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_huffman_encode_blocks: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    // input: [zz 128 B][prev_dc 2 B][class 1 B] per block; output: [bits 208 B][length 2 B] per block
+    const size_t in_zz = 128 * n_blocks, in_dc = (2 * n_blocks + 15) & ~size_t(15), in_cls = n_blocks;
+    const size_t out_bits = (size_t)kSlotWords * 4 * n_blocks, out_len = 2 * n_blocks;
+    int rc;
+    if ((rc = ensure(ctx, ctx->stage_in, in_zz + in_dc + in_cls))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, out_bits + out_len))) return rc;
+    uint8_t* din = (uint8_t*)ctx->stage_in.ptr;
+    uint8_t* dout = (uint8_t*)ctx->stage_out.ptr;
+    JEA_HIP(ctx, hipMemcpyAsync(din, h_zigzag, in_zz, hipMemcpyHostToDevice, ctx->stream));
+    JEA_HIP(ctx, hipMemcpyAsync(din + in_zz, h_prev_dc, 2 * n_blocks, hipMemcpyHostToDevice, ctx->stream));
+    JEA_HIP(ctx, hipMemcpyAsync(din + in_zz + in_dc, h_is_luminance, n_blocks, hipMemcpyHostToDevice, ctx->stream));
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    JEA_HIP(ctx, hipMemsetAsync(dout, 0, out_bits, ctx->stream));
+    launch_huffman_encode_blocks(ctx->stream, (const int16_t*)din, (const int16_t*)(din + in_zz), din + in_zz + in_dc,
+                                 n_blocks, ctx->d_huff, (uint16_t*)(dout + out_bits), (uint32_t*)dout, ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipMemcpyAsync(h_bits, dout, out_bits, hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipMemcpyAsync(h_lengths, dout + out_bits, out_len, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_status(ctx, ctx->d_status, "jea_huffman_encode_blocks");
+}
+
+int jea_stream_upload(jea_ctx* ctx, const uint8_t* h_stream, size_t len) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_stream || len == 0) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stream_upload: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stream_copy, len))) return rc;
+    JEA_HIP(ctx, hipMemcpyAsync(ctx->stream_copy.ptr, h_stream, len, hipMemcpyHostToDevice, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream_len = len;
+    return JEA_OK;
+}
+
+int jea_huffman_decode_block(jea_ctx* ctx, uint64_t start_bit, int is_luminance, int16_t* last_dc,
+                             int16_t h_zigzag[64], uint64_t* end_bit) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!last_dc || !h_zigzag || !end_bit || ctx->stream_len == 0 || start_bit >= 8 * (uint64_t)ctx->stream_len)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_huffman_decode_block: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->small, 256))) return rc;
+    uint8_t* d = (uint8_t*)ctx->small.ptr;  // [zz 128][end_bit 8][last_dc 4]
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    launch_huffman_decode_block(ctx->stream, (const uint8_t*)ctx->stream_copy.ptr, ctx->stream_len, start_bit,
+                                is_luminance != 0, (int)*last_dc, ctx->d_decode, (int16_t*)d, (uint64_t*)(d + 128),
+                                (int32_t*)(d + 136), ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    uint8_t h[144];
+    JEA_HIP(ctx, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = finish_status(ctx, ctx->d_status, "jea_huffman_decode_block"))) return rc;
+    std::memcpy(h_zigzag, h, 128);
+    std::memcpy(end_bit, h + 128, 8);
+    int32_t dc;
+    std::memcpy(&dc, h + 136, 4);
+    *last_dc = (int16_t)dc;
     return JEA_OK;
 }
 

@@ -1,0 +1,153 @@
+// Device functions of the colour / DCT / quantiser arithmetic, shared by the fused
+// image kernels (fdct.hip) and the per-block kernels (blocks.hip) so that both
+// run the very same instruction sequences.  Arithmetic contract: see fdct.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tables.h"
+
+namespace jea {
+
+// colour_mapping.cpp:48-51: floor(in + 0.5), clamp to [0, 255]
+__device__ __forceinline__ double round_to_range(double v) {
+    v = floor(v + 0.5);
+    v = (0.0 < v) ? v : 0.0;
+    v = (255.0 < v) ? 255.0 : v;
+    return v;
+}
+
+// One output channel of RGBToYCbCrMapper::applyMapping, colour_mapping.cpp:52-60.
+// Each formula there has the shape ((k + a*r) + b*g) + c*b evaluated left to
+// right in double; subtracting a product equals adding the product of the
+// negated constant, so one expression serves the three channels:
+//   Y  : k = 0,   a =  0.299,    b =  0.587,    c =  0.114
+//   Cb : k = 128, a = -0.168736, b = -0.331264, c =  0.5
+//   Cr : k = 128, a =  0.5,      b = -0.418688, c = -0.081312
+__device__ __forceinline__ double colour_forward(double k, double a, double b, double c, double r, double g,
+                                                 double bl) {
+    return round_to_range(((k + a * r) + b * g) + c * bl);
+}
+
+__device__ __forceinline__ void colour_constants(int channel, double& k, double& a, double& b, double& c) {
+    k = channel == 0 ? 0.0 : 128.0;
+    a = channel == 0 ? 0.299 : (channel == 1 ? -0.168736 : 0.5);
+    b = channel == 0 ? 0.587 : (channel == 1 ? -0.331264 : -0.418688);
+    c = channel == 0 ? 0.114 : (channel == 1 ? 0.5 : -0.081312);
+}
+
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) {
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+}
+
+// Forward-transform constants with the scale folded in where that is exact:
+// s(u) = 0.5 for u > 0 is a power of two, so  0.5 * sum_x C[u][x] f[x]  equals
+// sum_x (0.5 C[u][x]) f[x]  bit for bit (scaling by two commutes with every
+// rounding; nothing here comes near the subnormal range).  Row u = 0 has
+// C = 1 exactly, so its sum needs no products and keeps the final multiply by
+// s(0) = 0.5/sqrt(2), which is not a power of two.
+constexpr float fwd_c(int u, int x) { return u == 0 ? 1.0f : 0.5f * cos_c(u, x); }
+
+// Row pass of discrete_cosine_transform.cpp:103-112 for image row y of the block:
+//   row[u][y] = s(u) * (((C[u][0] f[0] + C[u][1] f[1]) + ...) + C[u][7] f[7])
+__device__ __forceinline__ void fdct_row(const float (&f)[8], int y, float (&row)[8][8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float acc = fwd_c(u, 0) * f[0];
+#pragma unroll
+        for (int x = 1; x < 8; ++x) acc += fwd_c(u, x) * f[x];
+        row[u][y] = (u == 0) ? scale_s(0) * acc : acc;
+    }
+}
+
+// Column pass :114-124 for horizontal frequency u: o[v] = out[8v+u].
+__device__ __forceinline__ void fdct_col(const float (&row)[8][8], int u, float (&o)[8]) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        float acc = fwd_c(v, 0) * row[u][0];
+#pragma unroll
+        for (int y = 1; y < 8; ++y) acc += fwd_c(v, y) * row[u][y];
+        o[v] = (v == 0) ? scale_s(0) * acc : acc;
+    }
+}
+
+// quantiser.cpp:57-70, literally: IEEE float divide, then 0.5 + and floor in double.
+__device__ __forceinline__ int quantise_exact(float o, float q) {
+    const float quot = o / q;
+    return (int)floor(0.5 + (double)quot);
+}
+
+// The same value from a reciprocal multiply.  t = o * rq differs from the
+// correctly rounded quotient by less than |t| * 2^-22 (rq = RN(1/q) and the
+// product each contribute at most 2^-24 relative, the reference's own division
+// another 2^-24), so floor(t + 0.5) is the reference's result unless t lies
+// within that distance of a half-integer; such lanes are flagged and redone
+// with quantise_exact.  v_cvt_rpi_i32_f32 is floor(x + 0.5) as an integer; its
+// own rounding of x + 0.5 is covered by the same margin.
+__device__ __forceinline__ int quantise_fast(float o, float rq, bool& ambiguous) {
+    const float t = o * rq;
+    int n;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(n) : "v"(t));
+    const float e = __builtin_fabsf(__builtin_amdgcn_fractf(t) - 0.5f);
+    ambiguous = e < __builtin_fabsf(t) * 0x1p-20f + 0x1p-22f;
+    return n;
+}
+
+// Quantises the eight coefficients out[8v+u], v = 0..7, of one column u.
+__device__ __forceinline__ void quantise_col(const float (&o)[8], const float* __restrict__ qt,
+                                             const float* __restrict__ rqt, int u, int* __restrict__ qv) {
+    bool any = false;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        bool amb;
+        qv[8 * v + u] = quantise_fast(o[v], rqt[8 * u + v], amb);  // tables are stored [u][v]
+        any |= amb;
+    }
+    if (__builtin_expect(any, 0)) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) qv[8 * v + u] = quantise_exact(o[v], qt[8 * u + v]);
+    }
+}
+
+// colour_mapping.cpp:77-85; (C - 128) is formed in integer arithmetic first.
+__device__ __forceinline__ void colour_inverse(int Y, int Cb, int Cr, uint8_t& r, uint8_t& g, uint8_t& b) {
+    const double y = (double)Y, cb = (double)(Cb - 128), cr = (double)(Cr - 128);
+    r = (uint8_t)round_to_range(y + 1.402 * cr);
+    g = (uint8_t)round_to_range((y - 0.344136 * cb) - 0.714136 * cr);
+    b = (uint8_t)round_to_range(y + 1.772 * cb);
+}
+
+constexpr float inv_c(int u, int x) { return scale_s(u) * cos_c(u, x); }  // fl32(s(u) * C[u][x]), :131,:142
+
+
+// Inverse transform of one dequantised block (natural order): row pass
+// discrete_cosine_transform.cpp:126-135, column pass with clamp and truncation
+// :136-156, level unshift :21-27.  px[8y+x] receives the u8 sample.
+__device__ __forceinline__ void idct_block(const float (&deq)[64], uint8_t (&px)[64]) {
+    float tmp[8][8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            float acc = inv_c(0, x) * deq[8 * v];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) acc += inv_c(u, x) * deq[u + 8 * v];
+            tmp[x][v] = acc;
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            float acc = inv_c(0, y) * tmp[x][0];
+#pragma unroll
+            for (int v = 1; v < 8; ++v) acc += inv_c(v, y) * tmp[x][v];
+            int o;
+            if (acc < -128.0f) o = -128;
+            else if (acc > 127.0f) o = 127;
+            else o = (int)acc;
+            px[8 * y + x] = (uint8_t)(o + 128);
+        }
+    }
+}
+
+}  // namespace jea

@@ -33,6 +33,7 @@
 // 256 threads of a workgroup touch consecutive addresses for equal w.
 #include <hip/hip_runtime.h>
 
+#include "huffman_device.h"
 #include "kernels.h"
 #include "tables.h"
 #include "../../include/jpegenc_amd.h"
@@ -44,124 +45,6 @@ namespace {
 constexpr int kEntThreads = 256;
 constexpr uint32_t kWinWords = 4096;  // 16 KiB LDS window of the packed stream
 constexpr uint32_t kFoldTiles = 4096;  // single images up to this many tiles skip the scan launches
-
-struct HuffLds {
-    uint32_t dc[2][12];
-    uint32_t ac[2][256];
-};
-
-__device__ __forceinline__ void load_huff(HuffLds& h, const HuffTables* __restrict__ g) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&h);
-    for (uint32_t i = threadIdx.x; i < sizeof(HuffLds) / 4; i += blockDim.x) dst[i] = src[i];
-}
-
-// The 64 zig-zag coefficients of one block-channel as loaded (8 x 16 bytes).
-struct BlockRegs {
-    uint32_t w[32];
-    __device__ __forceinline__ int at(int k) const { return (int)(int16_t)(w[k >> 1] >> (16 * (k & 1))); }
-};
-
-__device__ __forceinline__ void load_block(BlockRegs& r, const int16_t* __restrict__ p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint4 v = q[i];
-        r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
-    }
-}
-
-__device__ __forceinline__ uint32_t bit_width(uint32_t v) { return 32u - (uint32_t)__clz((int)v); }
-
-// Symbol generation for one block-channel, shared by the length pass and the
-// pack pass so that both see the same symbols.  Sink::put(bits, n) receives the
-// n low bits of `bits`, n in 1..27.
-//   DC  entropy_encoder.cpp:97, 715-730: SSSS = bit_width(|diff|); code; then the
-//       low SSSS bits of diff (diff > 0) or of ~|diff| (diff <= 0)
-//   AC  :101-118: (run, v) on every non-zero v, (15, 0) for each full run of 16
-//       zeros that is followed by a non-zero; EOB iff zz[63] == 0;  :732-765 codes
-// Returns false when a value falls outside the tables (SSSS > 11 / > 10).
-template <class Sink>
-__device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, const uint32_t* __restrict__ dc_tab,
-                                             const uint32_t* __restrict__ ac_tab, Sink& sink) {
-    bool ok = true;
-    {
-        const int diff = blk.at(0) - prev_dc;
-        const uint32_t amp = (uint32_t)(diff < 0 ? -diff : diff);
-        uint32_t s = bit_width(amp);
-        if (s > 11) { ok = false; s = 11; }
-        const uint32_t e = dc_tab[s];
-        const uint32_t extra = (diff > 0 ? amp : ~amp) & ((1u << s) - 1u);
-        sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
-    }
-    uint32_t run = 0;
-    // Coefficients are walked in groups of eight (one 16-byte load); a group that is
-    // all zero only extends the run.  High zig-zag positions are zero in most
-    // blocks, and a wave skips the group body when none of its lanes needs it.
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const uint32_t any = (g == 0 ? (blk.w[0] & 0xffff0000u) : blk.w[4 * g]) | blk.w[4 * g + 1] | blk.w[4 * g + 2] |
-                             blk.w[4 * g + 3];
-        if (any == 0) {
-            run += (g == 0) ? 7u : 8u;
-            continue;
-        }
-#pragma unroll
-        for (int k = (g == 0 ? 1 : 8 * g); k < 8 * g + 8; ++k) {
-            const int v = blk.at(k);
-            if (v != 0) {
-                while (run >= 16) {
-                    const uint32_t z = ac_tab[0xF0];
-                    sink.put(z & 0xffffu, z >> 16);
-                    run -= 16;
-                }
-                const uint32_t amp = (uint32_t)(v < 0 ? -v : v);
-                uint32_t s = bit_width(amp);
-                if (s > 10) { ok = false; s = 10; }
-                const uint32_t e = ac_tab[(run << 4) | s];
-                const uint32_t extra = (v > 0 ? amp : ~amp) & ((1u << s) - 1u);
-                sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
-                run = 0;
-            } else {
-                ++run;
-            }
-        }
-    }
-    if (run > 0) {  // zz[63] == 0: trailing zeros (and their ZRLs) collapse into EOB
-        const uint32_t e = ac_tab[0x00];
-        sink.put(e & 0xffffu, e >> 16);
-    }
-    return ok;
-}
-
-struct CountSink {
-    uint32_t bits = 0;
-    __device__ __forceinline__ void put(uint32_t, uint32_t n) { bits += n; }
-    __device__ __forceinline__ void finish() {}
-};
-
-// MSB-first writer into the block's slot: full words go out as they complete,
-// the last partial word is zero padded.
-struct SlotSink {
-    uint32_t* slot;  // &tile_slots[0][j]; word w is slot[w * kSlotStride]
-    uint32_t bits = 0;
-    uint64_t acc = 0;
-    uint32_t nacc = 0;
-    __device__ __forceinline__ void put(uint32_t v, uint32_t n) {
-        acc |= (uint64_t)v << (64u - nacc - n);
-        nacc += n;
-        bits += n;
-        if (nacc >= 32) {
-            *slot = (uint32_t)(acc >> 32);
-            slot += kSlotStride;
-            acc <<= 32;
-            nacc -= 32;
-        }
-    }
-    __device__ __forceinline__ void finish() {
-        if (nacc > 0) *slot = (uint32_t)(acc >> 32);
-    }
-};
 
 // Exclusive scan of one value per thread over a 256-thread workgroup.
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* lds4, uint32_t& total) {
@@ -533,68 +416,6 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
 // reference stream has no restart markers, encoder.cpp:121-137), the other lanes
 // stage stream bytes into LDS and store finished blocks.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kStreamWin = 2048;
-
-struct SerialReader {
-    const uint8_t* lds;     // staged raw bytes [base, base + kStreamWin + 16)
-    uint64_t base;          // file-relative index of lds[0]
-    uint64_t pos;           // next raw byte to take
-    uint64_t scan_end;      // file length - 2: stuffing is only removed before this index (bit_stream.cpp:137)
-    uint64_t len;           // file length
-    uint64_t buf;           // bit buffer, MSB first
-    int nbits;              // valid bits in buf
-    int phantom;            // zero bytes appended after the end of the file
-    __device__ __forceinline__ uint32_t raw(uint64_t i) const { return i < len ? lds[i - base] : 0u; }
-    __device__ __forceinline__ void refill() {
-        while (nbits <= 56) {
-            uint32_t b = 0;
-            if (pos < len) {
-                b = raw(pos);
-                // bit_stream.cpp:138: a 0x00 that follows a 0xFF is dropped
-                if (b == 0xFFu && pos < scan_end && raw(pos + 1) == 0x00u) ++pos;
-            } else {
-                ++phantom;
-            }
-            ++pos;
-            buf |= (uint64_t)b << (56 - nbits);
-            nbits += 8;
-        }
-    }
-    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf >> (64 - n)); }
-    __device__ __forceinline__ void skip(int n) { buf <<= n; nbits -= n; }
-    // true when bits beyond the end of the file have been consumed
-    __device__ __forceinline__ bool past_end() const { return nbits < 8 * phantom; }
-};
-
-// entropy_encoder.cpp:786-806, :845-864
-__device__ __forceinline__ int read_amplitude(SerialReader& r, int ssss) {
-    const uint32_t bits = r.peek(ssss);
-    r.skip(ssss);
-    const uint32_t mask = (1u << ssss) - 1u;
-    if (bits >> (ssss - 1)) return (int)(bits & mask);
-    return -(int)(mask & ~bits);
-}
-
-// The reference grows a candidate code bit by bit from two bits until it equals
-// a code word of that length (entropy_encoder.cpp:767-778, :810-828); for these
-// prefix codes that is the canonical decode: 9-bit table first, then the
-// max-code-per-length walk of T.81 Annex F.2.2.3.  Returns -1 on an invalid code.
-__device__ __forceinline__ int decode_symbol(SerialReader& r, const DecodeTable& t) {
-    const uint32_t e = t.fast[r.peek(9)];
-    if (e) {
-        r.skip((int)(e >> 8));
-        return (int)(e & 0xffu);
-    }
-    const uint32_t p16 = r.peek(16);
-    for (int l = 10; l <= 16; ++l) {
-        const int code = (int)(p16 >> (16 - l));
-        if (code <= t.maxcode[l]) {
-            r.skip(l);
-            return t.vals[code + t.valoff[l]];
-        }
-    }
-    return -1;
-}
 
 __global__ __launch_bounds__(64) void entropy_decode_kernel(const uint8_t* __restrict__ scan,
                                                             const uint64_t* __restrict__ offsets,
@@ -636,47 +457,9 @@ __global__ __launch_bounds__(64) void entropy_decode_kernel(const uint8_t* __res
         if (lane == 0 && sh_err == 0) {
             rd.base = win_base;
             const int ch = (int)(b % 3u);
-            const DecodeTable& dct = t.tab[ch ? 2 : 0];
-            const DecodeTable& act = t.tab[ch ? 3 : 1];
-            int err = 0;
-            rd.refill();
-            const int s = decode_symbol(rd, dct);
-            int diff = 0;
-            if (s < 0 || s > 11) err = JEA_ERR_BAD_STREAM;
-            else if (s > 0) { rd.refill(); diff = read_amplitude(rd, s); }
-            // entropy_encoder.cpp:703-712 symbol loop; :122-144 restores all entries but the LAST
-            int k = 1, processed = 0;
-            bool pending = false;
-            int pend_run = 0, pend_val = 0;
-            while (!err) {
-                rd.refill();
-                const int sym = decode_symbol(rd, act);
-                if (sym < 0) { err = JEA_ERR_BAD_STREAM; break; }
-                int run, val;
-                if (sym == 0x00) { run = 0; val = 0; }
-                else if (sym == 0xF0) { run = 15; val = 0; }
-                else {
-                    run = sym >> 4;
-                    const int ss = sym & 15;
-                    if (ss == 0 || ss > 10) { err = JEA_ERR_BAD_STREAM; break; }
-                    rd.refill();
-                    val = read_amplitude(rd, ss);
-                }
-                if (pending) {  // the previous entry is now known not to be the last: restore it
-                    k += pend_run;
-                    if (k < 64) zz[k] = (int16_t)pend_val;
-                    ++k;
-                }
-                pending = true; pend_run = run; pend_val = val;
-                processed += 1 + run;
-                if (processed > 63) { err = JEA_ERR_BAD_STREAM; break; }
-                if ((run == 0 && val == 0) || processed == 63) break;
-            }
-            if (rd.past_end()) err = JEA_ERR_BAD_STREAM;
             int last = ch == 0 ? last_y : (ch == 1 ? last_cb : last_cr);
-            last = (int)(int16_t)(diff + last);
+            const int err = decode_block(rd, t.tab[ch ? 2 : 0], t.tab[ch ? 3 : 1], last, zz);
             if (ch == 0) last_y = last; else if (ch == 1) last_cb = last; else last_cr = last;
-            zz[0] = (int16_t)last;
             // everything before rd.pos - 9 has left the window for good (the bit buffer holds < 9 bytes)
             sh_pos = rd.pos > 16 ? rd.pos - 16 : 0;
             if (err) sh_err = err;

@@ -93,6 +93,20 @@ void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t*
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
                          const QuantTables& q, uint8_t* d_rgb);
 
+// Per-block (component granularity) launchers, blocks.hip.
+void launch_dct_forward_blocks(hipStream_t s, const uint8_t* d_in, size_t n, float* d_out);
+void launch_dct_inverse_blocks(hipStream_t s, const float* d_in, size_t n, uint8_t* d_out);
+void launch_quantise_blocks(hipStream_t s, const float* d_in, size_t n, const QuantTables& q, bool use_lum,
+                            int16_t* d_out);
+void launch_dequantise_blocks(hipStream_t s, const int16_t* d_in, size_t n, const QuantTables& q, bool use_lum,
+                              float* d_out);
+void launch_huffman_encode_blocks(hipStream_t s, const int16_t* d_zz, const int16_t* d_prev_dc, const uint8_t* d_is_lum,
+                                  size_t n, const HuffTables* d_huff, uint16_t* d_lengths, uint32_t* d_bits,
+                                  int32_t* d_status);
+void launch_huffman_decode_block(hipStream_t s, const uint8_t* d_stream, uint64_t len, uint64_t start_bit, bool is_lum,
+                                 int last_dc, const DecodeTables* d_tables, int16_t* d_zz, uint64_t* d_end_bit,
+                                 int32_t* d_last_dc, int32_t* d_status);
+
 void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc);
 void launch_ycbcr_to_rgb(hipStream_t s, const uint8_t* d_ycc, size_t n_pixels, uint8_t* d_rgb);
 

@@ -184,3 +184,40 @@ def ycbcr_to_rgb(ycc_triples):
     out = np.zeros_like(a)
     LIB.jo_ycbcr_to_rgb(_p(a), a.size // 3, _p(out))
     return out
+
+
+def fdct_blocks(samples_u8):
+    """Level shift + forward DCT of (n, 64) u8 sample blocks -> (n, 64) float32 (index u + 8v)."""
+    a = np.ascontiguousarray(samples_u8, np.uint8).reshape(-1, 64)
+    shifted = (a.astype(np.int16) - 128).astype(np.int8)
+    out = np.zeros(a.shape, np.float32)
+    for i in range(a.shape[0]):
+        LIB.jo_fdct(shifted[i].ctypes.data, out[i].ctypes.data)
+    return out
+
+
+def idct_blocks(dct_f32):
+    """Inverse DCT + level unshift of (n, 64) float32 -> (n, 64) u8."""
+    a = np.ascontiguousarray(dct_f32, np.float32).reshape(-1, 64)
+    tmp = np.zeros(64, np.int8)
+    out = np.zeros(a.shape, np.uint8)
+    for i in range(a.shape[0]):
+        LIB.jo_idct(a[i].ctypes.data, tmp.ctypes.data)
+        out[i] = (tmp.astype(np.int16) + 128).astype(np.uint8)
+    return out
+
+
+def quantise_blocks(dct_f32, table):
+    a = np.ascontiguousarray(dct_f32, np.float32).reshape(-1, 64)
+    out = np.zeros(a.shape, np.int16)
+    for i in range(a.shape[0]):
+        LIB.jo_quantise(a[i].ctypes.data, _p(table), out[i].ctypes.data)
+    return out
+
+
+def dequantise_blocks(q_i16, table):
+    a = np.ascontiguousarray(q_i16, np.int16).reshape(-1, 64)
+    out = np.zeros(a.shape, np.float32)
+    for i in range(a.shape[0]):
+        LIB.jo_dequantise(a[i].ctypes.data, _p(table), out[i].ctypes.data)
+    return out
