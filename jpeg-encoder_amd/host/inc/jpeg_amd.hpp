@@ -1,0 +1,380 @@
+// Host-side C++20 interface of the MI355X JPEG encoder: the dependency-injected
+// `jpeg::Encoder` API of wjgra/jpeg-encoder with its arithmetic moved behind the
+// C-ABI in include/jpegenc_amd.h (gfx950 kernels).
+//
+// Same class names, constructor shapes, method signatures and public data members
+// as the reference (paths relative to its root):
+//   jpeg/inc/bitmap_image.hpp   BitmapImageRGB {m_width, height, m_fileSize, m_imageData}
+//   jpeg/inc/jpeg_image.hpp     JPEGImage {m_width, m_height, m_fileSize, m_compressedImageData, m_supportsSaving}
+//   jpeg/inc/bit_stream.hpp     BitStream, BitStreamReadProgress
+//   jpeg/inc/block_grid.hpp     BlockGrid::Block, InputBlockGrid, OutputBlockGrid
+//   jpeg/inc/colour_mapping.hpp ColourMapper, RGBToRGBMapper, RGBToYCbCrMapper
+//   jpeg/inc/discrete_cosine_transform.hpp  DiscreteCosineTransformer, Separated/Naive
+//   jpeg/inc/quantiser.hpp      Quantiser
+//   jpeg/inc/entropy_encoder.hpp  EntropyEncoder, HuffmanEncoder
+//   jpeg/inc/encoder.hpp        Encoder, BaselineEncoder
+// so code written against the reference (examples/encode-decode.cpp:102-118)
+// compiles against this header unchanged.
+//
+// What is different underneath: Encoder::encode / ::decode do not loop over
+// blocks on the host.  Each injected component reports a device capability; when
+// all four have one, the whole image goes through jea_encode_host /
+// jea_decode_host in a handful of kernel launches.  The per-block public methods
+// (map, transform, quantise, encode, ...) are kept and also run on the GPU, one
+// small launch per call; they exist for unit tests and API compatibility, not
+// for speed.  A component without a device implementation makes encode/decode
+// fail with the reference's error convention ("[Error]: ..." on stdout).
+#ifndef JPEG_AMD_HPP_
+#define JPEG_AMD_HPP_
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <iterator>
+#include <memory>
+#include <string>
+#include <vector>
+
+struct jea_ctx;
+
+namespace jpeg {
+
+// ---- markers (jpeg/inc/markers.hpp:5-12) -------------------------------------
+inline constexpr uint16_t markerStartOfImageSegmentSOI{0xFFD8};
+inline constexpr uint16_t markerJFIFImageSegmentAPP0{0xFFE0};
+inline constexpr uint16_t markerCommentSegmentCOM{0xFFFE};
+inline constexpr uint16_t markerDefineQuantisationTableSegmentDQT{0xFFDB};
+inline constexpr uint16_t markerStartOfFrame0SOF0{0xFFC0};
+inline constexpr uint16_t markerDefineHuffmanTableSegmentDHT{0xFFC4};
+inline constexpr uint16_t markerStartOfScanSegmentSOS{0xFFDA};
+inline constexpr uint16_t markerEndOfImageSegmentEOI{0xFFD9};
+
+// ---- images --------------------------------------------------------------------
+
+/* 24-bit RGB bitmap, row-major, top-down (jpeg/inc/bitmap_image.hpp:14-28).  The
+   file constructors read uncompressed 24-bit BMP files directly; the reference
+   uses SDL for that (bitmap_image.cpp:15-67), which this build does not need. */
+struct BitmapImageRGB {
+    BitmapImageRGB();
+    BitmapImageRGB(uint16_t w, uint16_t h);
+    BitmapImageRGB(std::string const& loadPath);
+    BitmapImageRGB(uint8_t const* buffer, int len);
+    struct PixelData {
+        uint8_t r, g, b;
+    };
+    uint16_t m_width, height;
+    std::uintmax_t m_fileSize;
+    std::vector<PixelData> m_imageData;
+    /* Writes a 24-bit BMP (not in the reference, whose demo only displays the bitmap). */
+    bool saveToFile(std::string const& path) const;
+
+private:
+    bool parse(uint8_t const* buffer, size_t len);
+};
+
+struct BitStreamReadProgress {
+    size_t currentByte;
+    size_t currentBit;
+    BitStreamReadProgress();
+    void reset();
+    void advanceBits(size_t numBits);
+    void advanceBit();
+    void advanceIntoAlignment();
+};
+
+/* MSB-first bit container (jpeg/inc/bit_stream.hpp:24-45).  In this build it is
+   the result container and the header writer; scan data arrives from the GPU as
+   whole bytes through appendBytes(). */
+class BitStream {
+public:
+    BitStream();
+    void clearStream();
+    size_t getSize();
+    void pushBitsu8(uint8_t data, size_t numberOfBitsToPush);
+    void pushBitsu16(uint16_t data, size_t numberOfBitsToPush);
+    uint8_t readByte(size_t byte) const;
+    void pushByte(uint8_t data);
+    void pushWord(uint16_t data);
+    void pushIntoAlignment();
+    bool readNextBit(BitStreamReadProgress& progress) const;
+    uint8_t readNextAlignedByte(BitStreamReadProgress& progress) const;
+    uint16_t readNextAlignedWord(BitStreamReadProgress& progress) const;
+    uint8_t const* getDataPtr() const;
+    void stuffBytes(size_t from);
+    void removeStuffedBytes(BitStreamReadProgress const& progress);
+    /* Additions of this build. */
+    void appendBytes(uint8_t const* data, size_t len);  // byte-aligned streams only
+    uint64_t revision() const { return m_revision; }     // changes whenever the contents change
+    size_t committedBytes() const { return m_stream.size(); }
+
+private:
+    uint8_t m_buffer;
+    size_t m_bitsInBuffer;
+    std::vector<uint8_t> m_stream;
+    uint64_t m_revision = 0;
+};
+
+struct JPEGImage {
+    uint16_t m_width, m_height;
+    std::uintmax_t m_fileSize;
+    BitStream m_compressedImageData;
+    bool m_supportsSaving = false;
+    /* As in the reference (jpeg_image.hpp:19-28) the file is opened in append mode. */
+    void saveToFile(std::string const& path);
+};
+
+// ---- block grid (jpeg/inc/block_grid.hpp) --------------------------------------
+
+class BlockGrid {
+protected:
+    BlockGrid() = default;
+
+public:
+    uint8_t const static blockSize = 8;
+    uint8_t const static blockElements = blockSize * blockSize;
+    struct Block {
+        std::array<BitmapImageRGB::PixelData, blockElements> m_blockPixelData;
+    };
+};
+
+class InputBlockGrid : public BlockGrid {
+public:
+    InputBlockGrid(BitmapImageRGB const& input);
+    struct BlockIterator {
+        using difference_type = std::ptrdiff_t;
+        using value_type = BlockGrid::Block;
+        using underlying_type = BitmapImageRGB::PixelData;
+        using underlying_pointer = underlying_type const*;
+        using iterator_category = std::input_iterator_tag;
+
+    private:
+        underlying_pointer m_ptr = nullptr;
+        uint16_t m_blockRowPos = 0, m_blockColPos = 0;
+        uint16_t m_gridWidth = 0, m_gridHeight = 0;
+
+    public:
+        explicit BlockIterator() = default;
+        BlockIterator(underlying_pointer p, uint16_t w, uint16_t h);
+        value_type operator*() const;
+        BlockIterator& operator++();
+        BlockIterator operator++(int);
+        friend bool operator==(BlockIterator const& a, BlockIterator const& b) { return a.m_ptr == b.m_ptr; }
+        friend bool operator!=(BlockIterator const& a, BlockIterator const& b) { return a.m_ptr != b.m_ptr; }
+        bool isLastCol() const;
+        bool isLastRow() const;
+        underlying_pointer getDataPtr() const;
+    };
+    BlockIterator begin() const;
+    BlockIterator end() const;
+
+private:
+    BitmapImageRGB const& m_imageData;
+};
+
+class OutputBlockGrid : public BlockGrid {
+public:
+    OutputBlockGrid() = delete;
+    OutputBlockGrid(uint16_t width, uint16_t height);
+    void processNextBlock(BlockGrid::Block const& inputBlock);
+    BitmapImageRGB getBitmapRGB() const;
+    bool atEnd() const;
+
+private:
+    BitmapImageRGB m_output;
+    InputBlockGrid m_blockGrid;
+    InputBlockGrid::BlockIterator m_currentBlock;
+    uint16_t const m_gridWidth, m_gridHeight;
+};
+
+// ---- device capabilities ---------------------------------------------------------
+/* What a component contributes to the fused GPU path.  `none` means the component
+   has no device implementation: the encoder then refuses to run (there is no host
+   fallback for image arithmetic in this build). */
+enum class DeviceColourMapping { none, rgbToYCbCr };
+enum class DeviceTransform { none, separatedFloat };
+enum class DeviceEntropyCoding { none, annexKHuffman };
+
+// ---- components ------------------------------------------------------------------
+
+struct ColourMappedBlockData {
+    using BlockChannelData = std::array<uint8_t, BlockGrid::blockElements>;
+    std::array<BlockChannelData, 3> m_data;
+};
+
+class ColourMapper {
+public:
+    ColourMapper() = default;
+    ColourMapper(ColourMapper const&) = delete;
+    ColourMapper(ColourMapper const&&) = delete;
+    ColourMapper& operator=(ColourMapper const&) = delete;
+    ColourMapper& operator=(ColourMapper const&&) = delete;
+    virtual ~ColourMapper() = default;
+
+    ColourMappedBlockData map(BlockGrid::Block const& inputBlock) const;
+    BlockGrid::Block unmap(ColourMappedBlockData const& inputBlock) const;
+    bool isLuminanceComponent(uint8_t component) const;
+    virtual DeviceColourMapping deviceCapability() const { return DeviceColourMapping::none; }
+
+protected:
+    virtual ColourMappedBlockData applyMapping(BlockGrid::Block const& inputBlock) const = 0;
+    virtual BlockGrid::Block reverseMapping(ColourMappedBlockData const& inputBlock) const = 0;
+    virtual bool componentIsLuminance(uint8_t component) const = 0;
+};
+
+/* Pass-through mapper (colour_mapping.cpp:16-42): pure data movement, kept on the
+   host; it has no device path, so an Encoder built with it reports an error. */
+class RGBToRGBMapper : public ColourMapper {
+protected:
+    ColourMappedBlockData applyMapping(BlockGrid::Block const& inputBlock) const override;
+    BlockGrid::Block reverseMapping(ColourMappedBlockData const& inputBlock) const override;
+    bool componentIsLuminance(uint8_t component) const override;
+};
+
+class RGBToYCbCrMapper : public ColourMapper {
+public:
+    DeviceColourMapping deviceCapability() const override { return DeviceColourMapping::rgbToYCbCr; }
+
+protected:
+    ColourMappedBlockData applyMapping(BlockGrid::Block const& inputBlock) const override;
+    BlockGrid::Block reverseMapping(ColourMappedBlockData const& inputBlock) const override;
+    bool componentIsLuminance(uint8_t component) const override;
+};
+
+struct DctBlockChannelData {
+    std::array<float, BlockGrid::blockElements> m_data;
+    float getDCCoefficient() { return m_data.front(); }
+};
+
+class DiscreteCosineTransformer {
+public:
+    DiscreteCosineTransformer() = default;
+    DiscreteCosineTransformer(DiscreteCosineTransformer const&) = delete;
+    DiscreteCosineTransformer(DiscreteCosineTransformer const&&) = delete;
+    DiscreteCosineTransformer& operator=(DiscreteCosineTransformer const&) = delete;
+    DiscreteCosineTransformer& operator=(DiscreteCosineTransformer const&&) = delete;
+    virtual ~DiscreteCosineTransformer() = default;
+
+    DctBlockChannelData transform(ColourMappedBlockData::BlockChannelData const& inputChannel) const;
+    ColourMappedBlockData::BlockChannelData inverseTransform(DctBlockChannelData const& inputChannel) const;
+    virtual DeviceTransform deviceCapability() const { return DeviceTransform::none; }
+
+protected:
+    std::array<int8_t, BlockGrid::blockElements> applyOffset(ColourMappedBlockData::BlockChannelData const& input) const;
+    virtual DctBlockChannelData applyTransform(std::array<int8_t, BlockGrid::blockElements> const& inputChannel) const = 0;
+    ColourMappedBlockData::BlockChannelData removeOffset(std::array<int8_t, BlockGrid::blockElements> const& input) const;
+    virtual std::array<int8_t, BlockGrid::blockElements> applyInverseTransform(DctBlockChannelData const& inputChannel) const = 0;
+};
+
+/* Separable 8x8 DCT in the reference's float operation order
+   (discrete_cosine_transform.cpp:77-156), executed on the GPU. */
+class SeparatedDiscreteCosineTransformer : public DiscreteCosineTransformer {
+public:
+    DeviceTransform deviceCapability() const override { return DeviceTransform::separatedFloat; }
+
+protected:
+    DctBlockChannelData applyTransform(std::array<int8_t, BlockGrid::blockElements> const& inputChannel) const override;
+    std::array<int8_t, BlockGrid::blockElements> applyInverseTransform(DctBlockChannelData const& inputChannel) const override;
+};
+
+struct QuantisedBlockChannelData {
+    std::array<int16_t, BlockGrid::blockElements> m_data;
+};
+
+class Quantiser {
+public:
+    Quantiser(int quality = 50);
+    QuantisedBlockChannelData quantise(DctBlockChannelData const& dctInput, bool useLuminanceMatrix) const;
+    DctBlockChannelData dequantise(QuantisedBlockChannelData const& quantisedInput, bool useLuminanceMatrix) const;
+    void encodeHeaderQuantisationTables(BitStream& outputStream) const;
+    /* Tables in natural order, for the device path. */
+    std::array<uint16_t, BlockGrid::blockElements> const& luminanceTable() const { return m_luminanceQuantisationMatrix; }
+    std::array<uint16_t, BlockGrid::blockElements> const& chrominanceTable() const { return m_chrominanceQuantisationMatrix; }
+
+private:
+    std::array<uint16_t, BlockGrid::blockElements> m_luminanceQuantisationMatrix;
+    std::array<uint16_t, BlockGrid::blockElements> m_chrominanceQuantisationMatrix;
+};
+
+struct RunLengthEncodedBlockChannelData {
+    int16_t m_dcDifference;
+    struct RunLengthEncodedACCoefficient {
+        size_t m_runLength;
+        int16_t m_value;
+        bool operator==(RunLengthEncodedACCoefficient const&) const = default;
+    };
+    std::vector<RunLengthEncodedACCoefficient> m_acCoefficients;
+};
+
+class EntropyEncoder {
+public:
+    EntropyEncoder() = default;
+    EntropyEncoder(EntropyEncoder const&) = delete;
+    EntropyEncoder(EntropyEncoder const&&) = delete;
+    EntropyEncoder& operator=(EntropyEncoder const&) = delete;
+    EntropyEncoder& operator=(EntropyEncoder const&&) = delete;
+    virtual ~EntropyEncoder() = default;
+
+    /* Per-block entry points of the reference (entropy_encoder.hpp:40-41): natural-order
+       coefficients in, bits appended to / read from the stream, DC predictor updated. */
+    virtual void encode(QuantisedBlockChannelData const& input, int16_t& lastDCValue, BitStream& outputStream,
+                        bool isLuminanceComponent) const = 0;
+    virtual QuantisedBlockChannelData decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
+                                             int16_t& lastDCValue, bool isLuminanceComponent) const = 0;
+    virtual void encodeHeaderEntropyTables(BitStream& outputStream) const = 0;
+    virtual DeviceEntropyCoding deviceCapability() const { return DeviceEntropyCoding::none; }
+};
+
+/* Annex-K Huffman coding; symbol generation, code lookup and bit packing run on the GPU. */
+class HuffmanEncoder : public EntropyEncoder {
+public:
+    HuffmanEncoder();
+    void encode(QuantisedBlockChannelData const& input, int16_t& lastDCValue, BitStream& outputStream,
+                bool isLuminanceComponent) const override;
+    QuantisedBlockChannelData decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
+                                     int16_t& lastDCValue, bool isLuminanceComponent) const override;
+    void encodeHeaderEntropyTables(BitStream& outputStream) const override;
+    DeviceEntropyCoding deviceCapability() const override { return DeviceEntropyCoding::annexKHuffman; }
+};
+
+// ---- encoder ---------------------------------------------------------------------
+
+class Encoder {
+public:
+    Encoder(Encoder const&) = delete;
+    Encoder(Encoder const&&) = delete;
+    Encoder& operator=(Encoder const&) = delete;
+    Encoder& operator=(Encoder const&&) = delete;
+    virtual ~Encoder();
+    Encoder(std::unique_ptr<ColourMapper> colourMapper,
+            std::unique_ptr<DiscreteCosineTransformer> discreteCosineTransformer,
+            std::unique_ptr<Quantiser> quantiser, std::unique_ptr<EntropyEncoder> entropyEncoder);
+    void encode(BitmapImageRGB const& inputImage, JPEGImage& outputImage);
+    void decode(JPEGImage inputImage, BitmapImageRGB& outputImage);
+    /* GPU the encoder uses (default 0); takes effect before the first encode/decode. */
+    void setDevice(int deviceId);
+
+private:
+    bool virtual supportsSaving() const = 0;
+    void requireDevicePath() const;
+    jea_ctx* context();
+
+    std::unique_ptr<ColourMapper> m_colourMapper;
+    std::unique_ptr<DiscreteCosineTransformer> m_discreteCosineTransformer;
+    std::unique_ptr<Quantiser> m_quantiser;
+    std::unique_ptr<EntropyEncoder> m_entropyEncoder;
+    jea_ctx* m_context = nullptr;
+    int m_device = 0;
+};
+
+class BaselineEncoder final : public Encoder {
+public:
+    BaselineEncoder(int quality)
+        : Encoder(std::make_unique<RGBToYCbCrMapper>(), std::make_unique<SeparatedDiscreteCosineTransformer>(),
+                  std::make_unique<Quantiser>(quality), std::make_unique<HuffmanEncoder>()) {}
+
+private:
+    bool supportsSaving() const override { return true; }
+};
+
+}  // namespace jpeg
+#endif

@@ -1,0 +1,177 @@
+// Exercises the C++ host interface the way callers of the reference use it
+// (examples/encode-decode.cpp:102-118 of the reference): BaselineEncoder(q),
+// encode(bitmap, jpeg), decode(jpeg, bitmap) -- and prints hashes that the Python
+// GPU test compares with the oracle's.  Also drives the per-block component
+// methods through the reference's own loop structure (encoder.cpp:14-42) and
+// checks that they give the same file as the fused path.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+
+#include "encoder.hpp"
+
+static uint64_t fnv(const uint8_t* d, size_t n, uint64_t basis) {
+    uint64_t h = basis;
+    for (size_t i = 0; i < n; ++i) { h ^= d[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+// Same synthetic images as oracle/jpeg_oracle.c jo_gen_image (std::mt19937 stream).
+static jpeg::BitmapImageRGB make_image(int w, int h, int mode, unsigned seed) {
+    jpeg::BitmapImageRGB bmp(static_cast<uint16_t>(w), static_cast<uint16_t>(h));
+    std::mt19937 rng(seed);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int r, g, b;
+            if (mode == 1) {
+                r = uint8_t(rng()); g = uint8_t(rng()); b = uint8_t(rng());
+            } else {
+                r = (x * 255) / (w > 1 ? w - 1 : 1);
+                g = (y * 255) / (h > 1 ? h - 1 : 1);
+                b = ((x + y) * 255) / (w + h);
+                r = std::min(255, r + int(rng() % 9));
+                g = std::max(0, g - int(rng() % 9));
+            }
+            bmp.m_imageData[size_t(y) * w + x] = {uint8_t(r), uint8_t(g), uint8_t(b)};
+        }
+    return bmp;
+}
+
+// The reference's per-block encode loop, written against the component interfaces only.
+static void encode_block_by_block(jpeg::BitmapImageRGB const& bmp, int quality, jpeg::BitStream& out) {
+    jpeg::RGBToYCbCrMapper mapper;
+    jpeg::SeparatedDiscreteCosineTransformer dct;
+    jpeg::Quantiser quantiser(quality);
+    jpeg::HuffmanEncoder huffman;
+    out.clearStream();
+    out.pushWord(jpeg::markerStartOfImageSegmentSOI);
+    out.pushWord(jpeg::markerJFIFImageSegmentAPP0);
+    out.pushWord(16);
+    for (char c : {'J', 'F', 'I', 'F'}) out.pushByte(uint8_t(c));
+    out.pushByte(0); out.pushWord(0x0102); out.pushByte(0); out.pushWord(0x0010); out.pushWord(0x0010); out.pushWord(0);
+    quantiser.encodeHeaderQuantisationTables(out);
+    out.pushWord(jpeg::markerStartOfFrame0SOF0);
+    out.pushWord(17); out.pushByte(8); out.pushWord(bmp.height); out.pushWord(bmp.m_width); out.pushByte(3);
+    out.pushByte(1); out.pushByte(0x11); out.pushByte(0);
+    out.pushByte(2); out.pushByte(0x11); out.pushByte(1);
+    out.pushByte(3); out.pushByte(0x11); out.pushByte(1);
+    huffman.encodeHeaderEntropyTables(out);
+    out.pushWord(jpeg::markerStartOfScanSegmentSOS);
+    out.pushWord(12); out.pushByte(3);
+    out.pushByte(1); out.pushByte(0x00); out.pushByte(2); out.pushByte(0x11); out.pushByte(3); out.pushByte(0x11);
+    out.pushWord(0x003F); out.pushByte(0);
+    const size_t scanStart = out.getSize();
+    jpeg::InputBlockGrid grid(bmp);
+    int16_t lastDC[3] = {0, 0, 0};
+    for (auto it = grid.begin(); it != grid.end(); ++it) {
+        jpeg::ColourMappedBlockData mapped = mapper.map(*it);
+        for (uint8_t ch = 0; ch < 3; ++ch) {
+            auto dctData = dct.transform(mapped.m_data[ch]);
+            auto q = quantiser.quantise(dctData, mapper.isLuminanceComponent(ch));
+            huffman.encode(q, lastDC[ch], out, mapper.isLuminanceComponent(ch));
+        }
+    }
+    out.stuffBytes(scanStart);
+    out.pushIntoAlignment();
+    out.pushWord(jpeg::markerEndOfImageSegmentEOI);
+}
+
+// The reference's per-block decode loop (encoder.cpp:44-71) on the component interfaces.
+static jpeg::BitmapImageRGB decode_block_by_block(jpeg::JPEGImage jpg, int quality) {
+    jpeg::RGBToYCbCrMapper mapper;
+    jpeg::SeparatedDiscreteCosineTransformer dct;
+    jpeg::Quantiser quantiser(quality);
+    jpeg::HuffmanEncoder huffman;
+    jpeg::OutputBlockGrid grid(jpg.m_width, jpg.m_height);
+    jpeg::BitStreamReadProgress progress;
+    progress.currentByte = 607;
+    jpg.m_compressedImageData.removeStuffedBytes(progress);
+    int16_t lastDC[3] = {0, 0, 0};
+    while (!grid.atEnd()) {
+        jpeg::ColourMappedBlockData block;
+        for (uint8_t ch = 0; ch < 3; ++ch) {
+            auto q = huffman.decode(jpg.m_compressedImageData, progress, lastDC[ch], mapper.isLuminanceComponent(ch));
+            block.m_data[ch] = dct.inverseTransform(quantiser.dequantise(q, mapper.isLuminanceComponent(ch)));
+        }
+        grid.processNextBlock(mapper.unmap(block));
+    }
+    if (jpg.m_compressedImageData.readNextAlignedWord(progress) != jpeg::markerEndOfImageSegmentEOI)
+        std::printf("blockwise_decode_eoi_missing\n");
+    return grid.getBitmapRGB();
+}
+
+int main(int argc, char** argv) {
+    const uint64_t basis = 0x14650fb0739d0383ull;
+    struct Case { int w, h, q, mode; };
+    const Case cases[] = {{512, 512, 75, 0}, {512, 512, 75, 1}, {13, 7, 75, 1}, {17, 33, 90, 1}, {8, 8, 50, 0},
+                          {1, 1, 75, 1}, {1920, 1080, 90, 0}};
+    for (const Case& c : cases) {
+        jpeg::BitmapImageRGB bmp = make_image(c.w, c.h, c.mode, 1234);
+        jpeg::BaselineEncoder encoder(c.q);
+        jpeg::JPEGImage jpg;
+        encoder.encode(bmp, jpg);
+        jpeg::BitmapImageRGB dec;
+        encoder.decode(jpg, dec);
+        std::printf("case %d %d %d %d bytes %zu jpeg %016llx rgb %016llx saving %d dims %u %u\n", c.w, c.h, c.q, c.mode,
+                    size_t(jpg.m_fileSize),
+                    (unsigned long long)fnv(jpg.m_compressedImageData.getDataPtr(), jpg.m_compressedImageData.getSize(), basis),
+                    (unsigned long long)fnv(reinterpret_cast<const uint8_t*>(dec.m_imageData.data()), dec.m_imageData.size() * 3, basis),
+                    int(jpg.m_supportsSaving), unsigned(dec.m_width), unsigned(dec.height));
+    }
+    {   // per-block component methods against the fused path
+        jpeg::BitmapImageRGB bmp = make_image(43, 21, 1, 77);
+        jpeg::BaselineEncoder encoder(80);
+        jpeg::JPEGImage jpg;
+        encoder.encode(bmp, jpg);
+        jpeg::BitStream blockwise;
+        encode_block_by_block(bmp, 80, blockwise);
+        const bool same = blockwise.getSize() == jpg.m_compressedImageData.getSize() &&
+                          std::memcmp(blockwise.getDataPtr(), jpg.m_compressedImageData.getDataPtr(), blockwise.getSize()) == 0;
+        std::printf("blockwise_encode_matches %d bytes %zu\n", int(same), blockwise.getSize());
+        jpeg::BitmapImageRGB fused;
+        encoder.decode(jpg, fused);
+        jpeg::BitmapImageRGB perBlock = decode_block_by_block(jpg, 80);
+        const bool sameDec = fused.m_imageData.size() == perBlock.m_imageData.size() &&
+                             std::memcmp(fused.m_imageData.data(), perBlock.m_imageData.data(), fused.m_imageData.size() * 3) == 0;
+        std::printf("blockwise_decode_matches %d\n", int(sameDec));
+    }
+    {   // an injected component without a GPU implementation: error printed, no throw, no output
+        class PassThrough final : public jpeg::Encoder {
+        public:
+            PassThrough() : Encoder(std::make_unique<jpeg::RGBToRGBMapper>(), std::make_unique<jpeg::SeparatedDiscreteCosineTransformer>(),
+                                    std::make_unique<jpeg::Quantiser>(50), std::make_unique<jpeg::HuffmanEncoder>()) {}
+        private:
+            bool supportsSaving() const override { return false; }
+        } passThrough;
+        jpeg::BitmapImageRGB bmp = make_image(16, 16, 0, 1);
+        jpeg::JPEGImage jpg;
+        passThrough.encode(bmp, jpg);
+        std::printf("no_device_path_size %zu\n", jpg.m_compressedImageData.getSize());
+    }
+    {   // damaged header: the reference's message on stdout, output untouched
+        jpeg::BitmapImageRGB bmp = make_image(16, 16, 0, 1);
+        jpeg::BaselineEncoder encoder(75);
+        jpeg::JPEGImage jpg;
+        encoder.encode(bmp, jpg);
+        jpeg::JPEGImage broken;
+        broken.m_width = 16; broken.m_height = 16;
+        std::vector<uint8_t> bytes(jpg.m_compressedImageData.getDataPtr(), jpg.m_compressedImageData.getDataPtr() + jpg.m_compressedImageData.getSize());
+        bytes[1] = 0;
+        broken.m_compressedImageData.appendBytes(bytes.data(), bytes.size());
+        jpeg::BitmapImageRGB dec;
+        encoder.decode(broken, dec);
+        std::printf("broken_header_pixels %zu\n", dec.m_imageData.size());
+    }
+    if (argc > 1) {  // BMP round trip through files
+        std::string dir = argv[1];
+        jpeg::BitmapImageRGB bmp = make_image(37, 19, 1, 5);
+        bmp.saveToFile(dir + "/in.bmp");
+        jpeg::BitmapImageRGB loaded(dir + "/in.bmp");
+        const bool same = loaded.m_width == 37 && loaded.height == 19 &&
+                          std::memcmp(loaded.m_imageData.data(), bmp.m_imageData.data(), 37 * 19 * 3) == 0;
+        std::printf("bmp_round_trip %d\n", int(same));
+    }
+    return 0;
+}
