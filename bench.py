@@ -107,14 +107,13 @@ def main():
     ctx.synchronize()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     assert int(d_status[0].item()) == 0
 
+    # whole-job throughput: all ranks' pixels over the slowest rank's time
     pixels_per_step = args.batch * W * H
-    value = world * args.steps * pixels_per_step / elapsed / 1e6
+    sharding = importlib.import_module("jpeg-encoder_amd.sharding")
+    rate, elapsed = sharding.job_throughput(args.steps * pixels_per_step, elapsed, dist, dev)
+    value = rate / 1e6
 
     # ---- roofline of the fused colour+FDCT+quantise+zigzag kernel, live, on the library's stream ----
     ext = torch.cuda.ExternalStream(ctx.stream_handle, device=dev)
