@@ -131,8 +131,14 @@ def main():
     k1_ms = e0.elapsed_time(e1) / reps
     k1_bytes = K1_BYTES_PER_PIXEL * pixels_per_step
     achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters, collected in separate rocprofv3 passes on this same command
+    # and corrected for gfx950 as profiles/r01_pmc_traffic.json describes; only valid for the workload it was taken on
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if args.batch == 1 and args.mode == 0 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["kernels"].get("fdct_quant_kernel", {}).get("hbm_bytes_per_launch")
     roofline = {"kernel": "fdct_quant_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_us": round(k1_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(k1_bytes)}
 
     cpu_baseline = None
