@@ -107,6 +107,31 @@ int jea_encode_host(jea_ctx* ctx, const uint8_t* h_rgb, uint16_t width, uint16_t
                     const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* h_out, size_t out_capacity,
                     size_t* out_len);
 
+/* ---- one image as MCU-row stripes on several contexts / GPUs -----------
+ * The reference codes an image as one serial chain (encoder.cpp:20-28): the DC
+ * predictors and the bit position carry from MCU to MCU.  A stripe (a run of
+ * whole MCU rows; every stripe but the last must be a multiple of 8 pixel rows
+ * high) can still be encoded on its own context when three small facts travel
+ * between the stripes' owners, in this order:
+ *   1. jea_stripe_transform: transform the stripe; yields the quantised DC values
+ *      of its last MCU.  -> every stripe needs the values of the stripe above.
+ *   2. jea_stripe_bits: Huffman-code the stripe with that DC start; yields its bit
+ *      count and the first 32 bits of its stream.  -> every stripe needs the sum
+ *      of the counts above it and the head bits of the stripe below.
+ *   3. jea_stripe_finish: pack at the global bit offset, byte-stuff; writes the
+ *      stripe's segment of the file (the first stripe's starts with the header,
+ *      the last one's ends with padding and EOI).
+ * The file is the segments concatenated in stripe order.  The caller moves the
+ * facts (all-gather between ranks, or a loop in one process). */
+int jea_stripe_transform(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t width, uint16_t stripe_height,
+                         const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t last_dc[3]);
+int jea_stripe_bits(jea_ctx* ctx, const int16_t prev_dc[3], uint64_t* total_bits, uint32_t* head_bits);
+/* is_first: write the 607-byte header for an image_width x image_height image first.
+ * has_next: a stripe follows; next_head_bits are the head bits it reported. */
+int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_next, uint32_t next_head_bits,
+                      uint16_t image_width, uint16_t image_height, const uint16_t lum_q[64],
+                      const uint16_t chr_q[64], uint8_t* d_segment, size_t capacity, size_t* segment_bytes);
+
 /* ---- whole decode: Encoder::decode, encoder.cpp:44-71 ------------------ */
 
 /* Decodes n_images JPEG files produced by this encoder family (fixed header

@@ -15,6 +15,7 @@ EXPORTS = [
     "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_get_stream", "jea_synchronize",
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
+    "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
     "jea_decode_batch", "jea_decode_host",
     "jea_fdct_quant", "jea_fdct_quant_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
     "jea_rgb_to_ycbcr", "jea_ycbcr_to_rgb",
@@ -64,6 +65,9 @@ def load_library():
     lib.jea_encode_batch.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp]
     lib.jea_encode_batch_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
     lib.jea_encode_host.argtypes = [vp, vp, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
+    lib.jea_stripe_transform.argtypes = [vp, vp, u16, u16, vp, vp, vp]
+    lib.jea_stripe_bits.argtypes = [vp, vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint32)]
+    lib.jea_stripe_finish.argtypes = [vp, c.c_uint64, i32, i32, c.c_uint32, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
     lib.jea_decode_batch.argtypes = [vp, vp, vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_decode_host.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_fdct_quant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
@@ -271,6 +275,28 @@ class Context:
         self._check(self.lib.jea_huffman_decode_block(self.handle, start_bit, int(is_lum), ctypes.byref(dc),
                                                       zz.ctypes.data, ctypes.byref(end)))
         return zz, end.value, dc.value
+
+    # ---- stripes of one image ----
+    def stripe_transform(self, d_rgb_stripe, w, stripe_h, lum, chrom):
+        dc = np.zeros(3, np.int16)
+        self.torch.cuda.synchronize(self.tdev)
+        self._check(self.lib.jea_stripe_transform(self.handle, d_rgb_stripe.data_ptr(), w, stripe_h, lum.ctypes.data,
+                                                  chrom.ctypes.data, dc.ctypes.data))
+        return [int(v) for v in dc]
+
+    def stripe_bits(self, prev_dc):
+        dc = np.asarray(prev_dc, np.int16)
+        bits, head = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        self._check(self.lib.jea_stripe_bits(self.handle, dc.ctypes.data, ctypes.byref(bits), ctypes.byref(head)))
+        return bits.value, head.value
+
+    def stripe_finish(self, bits_before, is_first, has_next, next_head, image_w, image_h, lum, chrom, capacity):
+        seg = self.empty(capacity, self.torch.uint8)
+        n = ctypes.c_size_t(0)
+        self._check(self.lib.jea_stripe_finish(self.handle, bits_before, int(is_first), int(has_next), next_head, image_w,
+                                               image_h, lum.ctypes.data, chrom.ctypes.data, seg.data_ptr(), capacity,
+                                               ctypes.byref(n)))
+        return seg[: n.value]
 
     # ---- whole path ----
     def encode_batch(self, d_rgb, n_images, w, h, lum, chrom, capacity=None, d_out=None):

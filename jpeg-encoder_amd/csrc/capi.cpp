@@ -43,6 +43,11 @@ struct jea_ctx {
     DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
     DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
     size_t stream_len = 0;
+    // stripe encode in progress (jea_stripe_*)
+    size_t stripe_mcus = 0;
+    uint16_t stripe_height = 0;
+    int stripe_stage = 0;  // 0 none, 1 transformed, 2 bits known
+    size_t stripe_capacity = 0;
 };
 
 namespace {
@@ -586,6 +591,96 @@ int jea_encode_host(jea_ctx* ctx, const uint8_t* h_rgb, uint16_t width, uint16_t
                                 ctx->stream));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out_len = (size_t)size;
+    return JEA_OK;
+}
+
+// ---- stripes --------------------------------------------------------------------
+
+int jea_stripe_transform(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t width, uint16_t stripe_height,
+                         const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t last_dc[3]) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb_stripe || !last_dc || !valid_dims(width, stripe_height) || !tables_ok(lum_q, chr_q))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_transform: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mcus = mcus_of(width, stripe_height);
+    int rc;
+    if ((rc = ensure(ctx, ctx->coefs, mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    // worst-case scratch for the later steps, so that they never reallocate between launches
+    EntropyScratch sc;
+    const size_t worst = (mcus * 3 * 1660 + 7) / 8 + 64;
+    if ((rc = prepare_entropy_scratch(ctx, 1, mcus, worst, sc))) return rc;
+    int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
+    launch_fdct_quant(ctx->stream, d_rgb_stripe, 1, width, stripe_height, to_float_tables(lum_q, chr_q), d_coefs,
+                      ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    for (int ch = 0; ch < 3; ++ch)
+        JEA_HIP(ctx, hipMemcpyAsync(&last_dc[ch], d_coefs + ((mcus - 1) * 3 + ch) * 64, sizeof(int16_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stripe_mcus = mcus;
+    ctx->stripe_height = stripe_height;
+    ctx->stripe_capacity = worst;
+    ctx->stripe_stage = 1;
+    return JEA_OK;
+}
+
+int jea_stripe_bits(jea_ctx* ctx, const int16_t prev_dc[3], uint64_t* total_bits, uint32_t* head_bits) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!prev_dc || !total_bits || !head_bits) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_bits: invalid argument");
+    if (ctx->stripe_stage != 1) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_bits: call jea_stripe_transform first");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    EntropyScratch sc;
+    int rc;
+    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc))) return rc;
+    if ((rc = ensure(ctx, ctx->small, 256))) return rc;
+    StripeInfo st;
+    for (int i = 0; i < 3; ++i) st.initial_dc[i] = prev_dc[i];
+    uint32_t* d_head = (uint32_t*)ctx->small.ptr;
+    launch_stripe_bits(ctx->stream, (const int16_t*)ctx->coefs.ptr, ctx->stripe_mcus, ctx->d_huff, sc, st, d_head,
+                       ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipMemcpyAsync(total_bits, sc.img_bits, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipMemcpyAsync(head_bits, d_head, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = finish_status(ctx, ctx->d_status, "jea_stripe_bits"))) return rc;
+    ctx->stripe_stage = 2;
+    return JEA_OK;
+}
+
+int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_next, uint32_t next_head_bits,
+                      uint16_t image_width, uint16_t image_height, const uint16_t lum_q[64],
+                      const uint16_t chr_q[64], uint8_t* d_segment, size_t capacity, size_t* segment_bytes) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_segment || !segment_bytes || capacity == 0 || !tables_ok(lum_q, chr_q) ||
+        !valid_dims(image_width, image_height))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_finish: invalid argument");
+    if (ctx->stripe_stage != 2) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_finish: call jea_stripe_bits first");
+    if (has_next && ctx->stripe_height % 8 != 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_finish: only the last stripe may have a height that is not a multiple of 8");
+    if (is_first && bits_before != 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_finish: the first stripe starts at bit 0");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    EntropyScratch sc;
+    int rc;
+    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc))) return rc;
+    if ((rc = ensure(ctx, ctx->out_offsets, sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->out_sizes, sizeof(uint64_t)))) return rc;
+    StripeInfo st;
+    st.bit_base = bits_before;
+    st.first_byte = (bits_before + 7) >> 3;
+    st.origin_byte = st.first_byte & ~uint64_t(3);
+    st.next_head = has_next ? next_head_bits : 0;
+    st.has_next = has_next ? 1 : 0;
+    st.active = 1;
+    HeaderBytes hb{};
+    if (is_first) jea_write_header(hb.b, image_width, image_height, lum_q, chr_q);
+    launch_stripe_finish(ctx->stream, ctx->stripe_mcus, sc, st, hb, is_first ? JEA_HEADER_BYTES : 0, !has_next, d_segment,
+                         capacity, (uint64_t*)ctx->out_offsets.ptr, (uint64_t*)ctx->out_sizes.ptr, ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    uint64_t size = 0;
+    JEA_HIP(ctx, hipMemcpyAsync(&size, ctx->out_sizes.ptr, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = finish_status(ctx, ctx->d_status, "jea_stripe_finish"))) return rc;
+    *segment_bytes = (size_t)size;
+    ctx->stripe_stage = 0;
     return JEA_OK;
 }
 

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
                                                                  uint16_t* __restrict__ len16,
                                                                  uint32_t* __restrict__ tile_bits,
                                                                  uint32_t* __restrict__ slots,
-                                                                 int32_t* __restrict__ status) {
+                                                                 int32_t* __restrict__ status, StripeInfo st) {
     __shared__ HuffLds h;
     __shared__ uint32_t wsum[4];
     load_huff(h, huff);
@@ -87,7 +87,9 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
         BlockRegs blk;
         load_block(blk, p);
         const int ch = (int)(b % 3u);
-        const int prev_dc = (b >= 3) ? (int)p[-192] : 0;  // same channel, previous MCU (encoder.cpp:20)
+        // same channel, previous MCU; the chain starts at 0 (encoder.cpp:20) or, in a
+        // stripe, at the last MCU of the stripe above
+        const int prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
         bool ok;
         if (kEmit) {
             SlotSink sink;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
                                                            uint8_t* __restrict__ unstuffed,
                                                            uint64_t unstuffed_capacity,
                                                            uint32_t* __restrict__ tile_ff,
-                                                           int32_t* __restrict__ status) {
+                                                           int32_t* __restrict__ status, StripeInfo st) {
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4];
     __shared__ uint64_t lsum[4];
@@ -266,13 +268,18 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     // 252 own block-channels + the first MCU of the next tile (threads 252..254)
     const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
-    const uint32_t my_len = has_block ? len16[(size_t)img * nbc + b] : 0;
+    // last tile of a stripe that has a successor: one thread stands in for the
+    // successor's first blocks with the 32 head bits it was given
+    const bool head_thread = st.has_next && tile + 1 == n_tiles && threadIdx.x == kTileBlocks;
+    const uint32_t my_len = has_block ? len16[(size_t)img * nbc + b] : (head_thread ? 32u : 0u);
     if (threadIdx.x == 0) ff_count = 0;
     uint32_t tile_total;
     const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);  // has barriers
 
     uint64_t base_bits, end_bits;
     tile_bit_range<kFold>(tile, n_tiles, tile_bits, tile_base, img_bits, img, lsum, base_bits, end_bits);
+    base_bits += st.bit_base;  // image-stream coordinates
+    end_bits += st.bit_base;
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1)
     const uint64_t d0 = base_bits >> 5;                      // image-relative dword of window word 0
     const uint32_t rel_start = (uint32_t)(base_bits & 31) + local_off;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
         if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
         return;
     }
-    uint8_t* dst = unstuffed + ubase;
+    uint8_t* dst = unstuffed + ubase - st.origin_byte;  // indexed by image-stream byte
 
     // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
     const uint32_t slot_tile = threadIdx.x < kTileBlocks ? tile : tile + 1;
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
         for (uint32_t w = 0; w < my_words; ++w) {
             const uint32_t idx = first + w - wlo;        // wraps below the window: rejected by the range test
             if (idx + 1 < kWinWords + 1 || idx == 0xffffffffu) {
-                const uint32_t v = slot[(size_t)w * kSlotStride];
+                const uint32_t v = head_thread ? st.next_head : slot[(size_t)w * kSlotStride];
                 if (idx < kWinWords) atomicOr(&win[idx], v >> sh);
                 if (sh != 0 && idx + 1 < kWinWords) atomicOr(&win[idx + 1], v << (32u - sh));
             }
@@ -346,13 +353,15 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
                                                             uint64_t* __restrict__ sizes, HeaderBytes header,
                                                             uint32_t header_len, uint32_t with_eoi,
                                                             uint8_t* __restrict__ out, uint64_t out_capacity,
-                                                            int32_t* __restrict__ status) {
+                                                            int32_t* __restrict__ status, StripeInfo st) {
     __shared__ uint32_t wsum[4];
     __shared__ uint64_t lsum[4];
     if (*status != 0) return;
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     uint64_t base_bits, end_bits;
     tile_bit_range<kFold>(tile, n_tiles, tile_bits, tile_base, img_bits, img, lsum, base_bits, end_bits);
+    base_bits += st.bit_base;
+    end_bits += st.bit_base;
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;
     uint64_t ff_before, file_offset;
     if (kFold) {
@@ -371,16 +380,27 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
     } else {
         ff_before = tile_ffbase[(size_t)img * n_tiles + tile];
         file_offset = offsets[img];
+        if (st.active) {
+            // a stripe's segment: its owned bytes start at st.first_byte; exact size known here
+            const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
+            if (header_len + (b1 - st.first_byte) + ff_before + tile_ff[(size_t)img * n_tiles + tile] + tail > out_capacity) {
+                if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
+                return;
+            }
+            if (tile + 1 == n_tiles && threadIdx.x == 0)
+                sizes[img] = header_len + (b1 - st.first_byte) + img_ff[img] + tail;
+        }
     }
-    const uint8_t* src = unstuffed + (kFold ? 0 : img_ubase[img]);
+    const uint8_t* src = unstuffed + (kFold ? 0 : img_ubase[img]) - st.origin_byte;  // indexed by image-stream byte
     uint8_t* file = out + file_offset;
-    uint8_t* dst = file + header_len + ff_before;  // + source index + 0xFFs before it inside the tile
+    // + image-stream byte index + 0xFFs before it inside the tile
+    uint8_t* dst = file + header_len + ff_before - st.first_byte;
 
     if (tile == 0)
         for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) file[i] = header.b[i];
     if (tile + 1 == n_tiles && with_eoi && threadIdx.x == 0) {
         const uint64_t ff_total = kFold ? ff_before + tile_ff[tile] : img_ff[img];
-        uint8_t* e = file + header_len + b1 + ff_total;
+        uint8_t* e = file + header_len + (b1 - st.first_byte) + ff_total;
         e[0] = 0xFF;
         e[1] = 0xD9;
     }
@@ -488,7 +508,7 @@ void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, 
     const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
     block_bits_kernel<false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
-        d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status);
+        d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status, StripeInfo{});
 }
 
 void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -502,17 +522,18 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const uint32_t eoi = with_eoi ? 1u : 0u;
 
     block_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                         sc.slots, d_status);
+                                                         sc.slots, d_status, StripeInfo{});
 
     if (n == 1 && n_tiles <= kFoldTiles) {
         // One image with few tiles: every workgroup sums the totals of the tiles
         // before it, which is cheaper than two dependent single-workgroup scans.
         pack_kernel<true><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, nullptr, nullptr,
                                                        nullptr, sc.unstuffed, sc.unstuffed_capacity, sc.tile_ff,
-                                                       d_status);
+                                                       d_status, StripeInfo{});
         stuff_kernel<true><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, nullptr, nullptr, nullptr, sc.unstuffed,
                                                         sc.tile_ff, nullptr, nullptr, d_offsets, d_sizes, header,
-                                                        (uint32_t)header_len, eoi, d_out, out_capacity, d_status);
+                                                        (uint32_t)header_len, eoi, d_out, out_capacity, d_status,
+                                                        StripeInfo{});
         return;
     }
 
@@ -522,7 +543,7 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
 
     pack_kernel<false><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
                                                     sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
-                                                    sc.tile_ff, d_status);
+                                                    sc.tile_ff, d_status, StripeInfo{});
 
     ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
     scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
@@ -531,7 +552,55 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     stuff_kernel<false><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
                                                      sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets,
                                                      d_sizes, header, (uint32_t)header_len, eoi, d_out, out_capacity,
-                                                     d_status);
+                                                     d_status, StripeInfo{});
+}
+
+namespace {
+// First 32 bits (MSB first, zero padded) of the stream that the blocks' strings form.
+__global__ void stripe_head_kernel(const uint16_t* __restrict__ len16, const uint32_t* __restrict__ slots,
+                                   uint32_t nbc, uint32_t* __restrict__ head) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t acc = 0, n = 0;
+    for (uint32_t b = 0; b < nbc && n < 32; ++b) {
+        const uint32_t len = len16[b];
+        const uint32_t* slot = slots + (size_t)(b / kTileBlocks) * kSlotWords * kSlotStride + (b % kTileBlocks);
+        for (uint32_t i = 0; i < len && n < 32; ++i, ++n) {
+            const uint32_t word = slot[(size_t)(i >> 5) * kSlotStride];
+            acc |= ((word >> (31u - (i & 31u))) & 1u) << (31u - n);
+        }
+    }
+    *head = acc;
+}
+}  // namespace
+
+void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, const HuffTables* d_huff,
+                        const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status) {
+    const uint32_t nbc = (uint32_t)(mcus * 3);
+    const uint32_t n_tiles = tiles_per_image(mcus);
+    block_bits_kernel<true><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
+                                                                     sc.slots, d_status, st);
+    ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
+    scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
+    stripe_head_kernel<<<1, 64, 0, s>>>(sc.len16, sc.slots, nbc, d_head);
+}
+
+void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, const StripeInfo& st,
+                          const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
+                          size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
+    const uint32_t nbc = (uint32_t)(mcus * 3);
+    const uint32_t n_tiles = tiles_per_image(mcus);
+    const dim3 grid(n_tiles, 1);
+    const uint32_t eoi = with_eoi ? 1u : 0u;
+    pack_kernel<false><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
+                                                    sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
+                                                    sc.tile_ff, d_status, st);
+    // the scan's own size estimate is only a capacity check here; the stuff pass writes the exact segment size
+    ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity + 8, (uint32_t)header_len + 2 * eoi, d_status};
+    scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
+    stuff_kernel<false><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
+                                                     sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets,
+                                                     d_sizes, header, (uint32_t)header_len, eoi, d_out, out_capacity,
+                                                     d_status, st);
 }
 
 void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,

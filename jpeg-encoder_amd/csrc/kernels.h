@@ -57,6 +57,22 @@ inline uint32_t tiles_per_image(size_t mcus_per_image) {
     return (uint32_t)((mcus_per_image * 3 + kTileBlocks - 1) / kTileBlocks);
 }
 
+// Position of an MCU-row stripe inside the entropy stream of its image, for
+// images whose stripes are encoded by different contexts / GPUs.  All zero for a
+// whole image.  The stripe's bit strings start `bit_base` bits into the image's
+// stream; it owns the stream bytes from first_byte = ceil(bit_base / 8) on, and
+// the byte it shares with the following stripe, which it completes with
+// `next_head` (the first 32 bits of that stripe's stream, MSB first).
+struct StripeInfo {
+    uint64_t bit_base = 0;
+    uint64_t first_byte = 0;   // ceil(bit_base / 8)
+    uint64_t origin_byte = 0;  // first_byte rounded down to 4: stream byte held at unstuffed[0]
+    uint32_t next_head = 0;
+    uint32_t has_next = 0;
+    uint32_t active = 0;       // non-zero: stripe mode (segment size written by the stuff pass)
+    int16_t initial_dc[3] = {0, 0, 0};  // quantised DC of the last MCU of the previous stripe
+};
+
 // Device-side bookkeeping of one encode pass; all arrays are caller-provided
 // scratch.  n_tiles = tiles per image, n = images.
 struct EntropyScratch {
@@ -85,6 +101,16 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
                            const HuffTables* d_huff, const EntropyScratch& sc, const HeaderBytes& header,
                            int header_len, bool with_eoi, uint8_t* d_out, size_t out_capacity,
                            uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
+
+// Stripe encode in two steps around the exchange of the stripes' bit totals:
+// bits: block bit strings (DC chain continued from st.initial_dc), per-tile scan,
+//       total -> sc.img_bits[0], first 32 stream bits -> d_head;
+// finish: pack at st.bit_base, 0xFF scan, stuffed segment (+ header / EOI) -> d_out, size -> d_sizes[0].
+void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, const HuffTables* d_huff,
+                        const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status);
+void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, const StripeInfo& st,
+                          const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
+                          size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
 
 void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
                            size_t n_images, size_t mcus_per_image, const DecodeTables* d_tables, int16_t* d_coefs,

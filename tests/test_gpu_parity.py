@@ -292,3 +292,50 @@ def test_full_size_round_trip_properties(ctx, po, jea):
     # idempotence: a second encode of the same resident image gives the same bytes
     out2, off2, size2 = ctx.encode_batch(d_rgb, 1, w, h, lum, chrom, capacity=64 << 20)
     assert size2[0] == size[0] and ctx.torch.equal(out2[: int(size[0])], out[: int(size[0])])
+
+
+@pytest.mark.parametrize("w,h,n_stripes,mode,quality", [
+    (64, 64, 2, 1, 75), (200, 120, 3, 0, 75), (200, 120, 5, 1, 90), (136, 77, 4, 1, 50), (16, 200, 8, 1, 100),
+    (1024, 512, 8, 0, 75), (520, 333, 7, 1, 75),
+])
+def test_striped_encode_equals_whole_image(ctx, po, jea, w, h, n_stripes, mode, quality):
+    """One image as MCU-row stripes, each through its own context with the three-step protocol: the
+    concatenated segments are the serial file, byte for byte (DC chain, bit phase and shared bytes stitched)."""
+    import importlib
+
+    stripes = importlib.import_module("jpeg-encoder_amd.stripes")
+    lum, chrom = jea.binding.quant_tables(quality)
+    rgb = po.gen_image(w, h, mode, 31)
+    rows = stripes.stripe_rows(h, n_stripes)
+    ctxs = [jea.Context(0) for _ in rows]
+    try:
+        backends = [stripes.HipBackend(c, c.to_device(rgb[y0:y1].reshape(-1)), w, y1 - y0, lum, chrom)
+                    for c, (y0, y1) in zip(ctxs, rows)]
+        got = stripes.encode_in_process(backends, w, h)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert got == po.encode(rgb, quality)
+
+
+def test_striped_encode_all_ff_boundaries(ctx, po, jea):
+    """Stripe boundaries inside runs of 0xFF bytes and at every bit phase."""
+    import importlib
+
+    stripes = importlib.import_module("jpeg-encoder_amd.stripes")
+    lum, chrom = jea.binding.quant_tables(100)
+    rng = np.random.RandomState(8)
+    w, h = 96, 96
+    rgb = (rng.randint(0, 2, (h, w, 3)) * 255).astype(np.uint8)   # saturated noise: long codes, many 0xFF bytes
+    want = po.encode(rgb, 100)
+    assert want.count(b"\xff\x00") > 50
+    for n in (2, 3, 4, 6, 12):
+        rows = stripes.stripe_rows(h, n)
+        ctxs = [jea.Context(0) for _ in rows]
+        try:
+            backends = [stripes.HipBackend(c, c.to_device(rgb[y0:y1].reshape(-1)), w, y1 - y0, lum, chrom)
+                        for c, (y0, y1) in zip(ctxs, rows)]
+            assert stripes.encode_in_process(backends, w, h) == want, n
+        finally:
+            for c in ctxs:
+                c.close()
