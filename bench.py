@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="images per step")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="contexts (HIP streams) the steps alternate over; independent images overlap")
     ap.add_argument("--mode", type=int, default=0, help="0 smooth gradients + noise, 1 uniform noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=10, help="images of the CPU sample")
@@ -63,7 +65,8 @@ def main():
 
     pkg = importlib.import_module("jpeg-encoder_amd")
     binding = pkg.binding
-    ctx = pkg.Context(local_rank)
+    ctxs = [pkg.Context(local_rank) for _ in range(max(1, args.streams))]
+    ctx = ctxs[0]
     dev = ctx.tdev
     lum, chrom = binding.quant_tables(QUALITY)
 
@@ -73,19 +76,32 @@ def main():
     imgs = np.stack([po.gen_image(W, H, args.mode, 1234 + rank * args.batch + i) for i in range(args.batch)])
     d_rgb = ctx.to_device(imgs.reshape(-1))
     cap = args.batch * (3 * W * H // 2 + (1 << 20)) if args.mode == 0 else args.batch * binding.max_jpeg_bytes(W, H)
-    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-    d_offsets = torch.zeros(args.batch, dtype=torch.int64, device=dev)
-    d_sizes = torch.zeros(args.batch, dtype=torch.int64, device=dev)
-    d_status = torch.zeros(16, dtype=torch.int32, device=dev)
+    # every context has its own output and bookkeeping buffers; the input images are shared (read only)
+    outs = [dict(out=torch.empty(cap, dtype=torch.uint8, device=dev),
+                 offsets=torch.zeros(args.batch, dtype=torch.int64, device=dev),
+                 sizes=torch.zeros(args.batch, dtype=torch.int64, device=dev),
+                 status=torch.zeros(16, dtype=torch.int32, device=dev)) for _ in ctxs]
+    d_out, d_offsets, d_sizes, d_status = (outs[0][k] for k in ("out", "offsets", "sizes", "status"))
     torch.cuda.synchronize(dev)
+    turn = [0]
 
     def step():
-        ctx.encode_batch_async(d_rgb, args.batch, W, H, lum, chrom, d_out, d_offsets, d_sizes, d_status)
+        i = turn[0] % len(ctxs)
+        turn[0] += 1
+        o = outs[i]
+        ctxs[i].encode_batch_async(d_rgb, args.batch, W, H, lum, chrom, o["out"], o["offsets"], o["sizes"], o["status"])
+
+    def sync_all():
+        for c in ctxs:
+            c.synchronize()
 
     # parity gate before timing: the first image's file must equal the oracle's, byte for byte
-    step()
-    ctx.synchronize()
-    assert int(d_status[0].item()) == 0, "encode reported status %d" % int(d_status[0].item())
+    for _ in ctxs:
+        step()
+    sync_all()
+    for o in outs:
+        assert int(o["status"][0].item()) == 0, "encode reported status %d" % int(o["status"][0].item())
+        assert torch.equal(o["out"][: int(o["sizes"][0].item())], d_out[: int(d_sizes[0].item())])
     off0, size0 = int(d_offsets[0].item()), int(d_sizes[0].item())
     gpu_file = d_out[off0: off0 + size0].cpu().numpy().tobytes()
     parity = gpu_file == po.encode(imgs[0], QUALITY)
@@ -95,7 +111,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        ctx.synchronize()
+        sync_all()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
@@ -104,10 +120,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ctx.synchronize()
+    sync_all()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    assert int(d_status[0].item()) == 0
+    assert all(int(o["status"][0].item()) == 0 for o in outs)
 
     # whole-job throughput: all ranks' pixels over the slowest rank's time
     pixels_per_step = args.batch * W * H
@@ -165,11 +181,12 @@ def main():
                        "%d x 3840x2160 RGB images encoded at q=75 per step" % args.batch,
                        "images_per_step": args.batch, "width": W, "height": H, "quality": QUALITY,
                        "jpeg_bytes_image0": size0, "byte_identical_to_oracle": parity,
-                       "sharding": "images by rank, no collective"},
+                       "streams": len(ctxs), "sharding": "images by rank, no collective"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

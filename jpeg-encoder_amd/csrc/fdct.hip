@@ -154,6 +154,87 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
     }
 }
 
+// Variant with one wave per workgroup and no LDS: lane = MCU, blockIdx.y = channel.
+// Each lane reads its own eight 24-byte row strips (neighbouring lanes read
+// neighbouring strips, so a wave's three loads of a row cover 1536 contiguous
+// bytes) and stores its own 128-byte coefficient block.  Work items are single
+// waves, which the dispatcher balances over the SIMDs far better than 3-wave
+// groups when one image is only a few waves per SIMD.
+template <bool kFast>
+__global__ __launch_bounds__(64) void fdct_quant_wave_kernel(const uint8_t* __restrict__ rgb, int width, int height,
+                                                             int blocks_w, uint32_t n_mcu, size_t image_bytes,
+                                                             QuantTables q, int16_t* __restrict__ coefs,
+                                                             int32_t* __restrict__ status_to_clear) {
+    if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        *status_to_clear = 0;
+    const int channel = blockIdx.y;
+    const uint32_t mcu = blockIdx.x * 64u + threadIdx.x;
+    if (mcu >= n_mcu) return;
+    const uint8_t* img = rgb + (size_t)blockIdx.z * image_bytes;
+    const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+    double ck, ca, cb, cc;
+    colour_constants(channel, ck, ca, cb, cc);
+
+    float row[8][8];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        int yy = (int)by * 8 + y;
+        yy = yy < height ? yy : height - 1;  // bottom edge: repeat the last row
+        uint32_t d[6];
+        if (kFast) {
+            const uint2* src = reinterpret_cast<const uint2*>(img + ((size_t)yy * width + bx * 8) * 3);
+            const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
+            d[0] = w0.x; d[1] = w0.y; d[2] = w1.x; d[3] = w1.y; d[4] = w2.x; d[5] = w2.y;
+        } else {
+            // any width: byte gather with the column clamp of block_grid.cpp:20-22
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                int xx = (int)bx * 8 + p;
+                xx = xx < width ? xx : width - 1;
+                const uint8_t* px = img + ((size_t)yy * width + xx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int byte = 3 * p + c;
+                    d[byte >> 2] |= (uint32_t)px[c] << (8 * (byte & 3));
+                }
+            }
+        }
+        float f[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
+            const double r = (double)((d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu);
+            const double g = (double)((d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu);
+            const double b = (double)((d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu);
+            const float rounded = (float)floor((((ck + ca * r) + cb * g) + cc * b) + 0.5);
+            f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
+        }
+        fdct_row(f, y, row);
+    }
+
+    const float* qt = channel == 0 ? q.lum_t : q.chr_t;
+    const float* rqt = channel == 0 ? q.rlum_t : q.rchr_t;
+    int qv[64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float o[8];
+        fdct_col(row, u, o);
+        quantise_col(o, qt, rqt, u, qv);
+    }
+    uint4* out = reinterpret_cast<uint4*>(coefs + (((size_t)blockIdx.z * n_mcu + mcu) * 3 + channel) * 64);
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+        uint4 chunk;
+        chunk.x = pack16(qv[kZigzag[8 * k8 + 0]], qv[kZigzag[8 * k8 + 1]]);
+        chunk.y = pack16(qv[kZigzag[8 * k8 + 2]], qv[kZigzag[8 * k8 + 3]]);
+        chunk.z = pack16(qv[kZigzag[8 * k8 + 4]], qv[kZigzag[8 * k8 + 5]]);
+        chunk.w = pack16(qv[kZigzag[8 * k8 + 6]], qv[kZigzag[8 * k8 + 7]]);
+        out[k8] = chunk;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Inverse: de-zigzag + dequantise + IDCT + level unshift + YCbCr->RGB + crop.
 // Same thread mapping as the forward kernel; the three channel planes of the 64
@@ -279,6 +360,16 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
     const bool fast = (width % 8 == 0) && ((reinterpret_cast<uintptr_t>(d_rgb) & 7u) == 0);
+#ifdef JEA_K1_WAVE
+    const dim3 wgrid((n_mcu + 63) / 64, 3, (unsigned)n_images);
+    if (fast)
+        fdct_quant_wave_kernel<true><<<wgrid, 64, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+                                                          d_status_to_clear);
+    else
+        fdct_quant_wave_kernel<false><<<wgrid, 64, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+                                                           d_status_to_clear);
+    return;
+#endif
     if (fast)
         fdct_quant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
                                                               d_status_to_clear);
