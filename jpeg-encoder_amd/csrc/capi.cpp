@@ -39,7 +39,7 @@ struct jea_ctx {
     DecodeTables* d_decode = nullptr;
     int32_t* d_status = nullptr;
     // scratch, grown on demand and kept
-    DeviceBuffer coefs, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
+    DeviceBuffer coefs, masks, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
     DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
     DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
     size_t stream_len = 0;
@@ -158,6 +158,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     const size_t ucap = (out_capacity + 16 * n_images < worst) ? out_capacity + 16 * n_images : worst;
     if ((rc = ensure(ctx, ctx->unstuffed, ucap))) return rc;
     sc.len16 = (uint16_t*)ctx->len16.ptr;
+    sc.chunk_masks = nullptr;  // set by callers whose coefficients come with masks from the forward kernel
     sc.slots = (uint32_t*)ctx->slots.ptr;
     sc.tile_bits = (uint32_t*)ctx->tile_bits.ptr;
     sc.tile_base = (uint64_t*)ctx->tile_base.ptr;
@@ -268,7 +269,7 @@ void jea_destroy(jea_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    for (DeviceBuffer* b : {&ctx->coefs, &ctx->len16, &ctx->slots, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
+    for (DeviceBuffer* b : {&ctx->coefs, &ctx->masks, &ctx->len16, &ctx->slots, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
                             &ctx->tile_ffbase, &ctx->img_words, &ctx->unstuffed, &ctx->stage_in, &ctx->stage_out,
                             &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small})
         free_buffer(*b);
@@ -425,7 +426,7 @@ int jea_fdct_quant_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, ui
         !tables_ok(lum_q, chr_q))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_fdct_quant: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
-    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, nullptr);
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, nullptr, nullptr);
     JEA_HIP(ctx, hipGetLastError());
     return JEA_OK;
 }
@@ -489,10 +490,11 @@ int jea_block_bit_lengths(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images,
 static int entropy_encode_common(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus,
                                  const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
                                  size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status,
-                                 bool status_is_clear) {
+                                 bool status_is_clear, const uint8_t* d_chunk_masks = nullptr) {
     EntropyScratch sc;
     int rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc);
     if (rc) return rc;
+    sc.chunk_masks = d_chunk_masks;
     if (!status_is_clear) JEA_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t), ctx->stream));
     launch_entropy_encode(ctx->stream, d_coefs, n_images, mcus, ctx->d_huff, sc, header, header_len, with_eoi, d_out,
                           out_capacity, d_offsets, d_sizes, d_status);
@@ -540,16 +542,19 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
     const size_t mcus = mcus_of(width, height);
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3))) return rc;
     int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
+    uint8_t* d_masks = (uint8_t*)ctx->masks.ptr;
     // scratch first: growing a buffer synchronises the stream, which must not happen between the launches
     EntropyScratch sc;
     if ((rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc))) return rc;
     HeaderBytes hb{};
     jea_write_header(hb.b, width, height, lum_q, chr_q);
-    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status);
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status,
+                      d_masks);
     JEA_HIP(ctx, hipGetLastError());
     return entropy_encode_common(ctx, d_coefs, n_images, mcus, hb, JEA_HEADER_BYTES, true, d_out, out_capacity,
-                                 d_offsets, d_sizes, d_status, true);
+                                 d_offsets, d_sizes, d_status, true, d_masks);
 }
 
 int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
@@ -605,13 +610,14 @@ int jea_stripe_transform(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t wid
     const size_t mcus = mcus_of(width, stripe_height);
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->masks, mcus * 3))) return rc;
     // worst-case scratch for the later steps, so that they never reallocate between launches
     EntropyScratch sc;
     const size_t worst = (mcus * 3 * 1660 + 7) / 8 + 64;
     if ((rc = prepare_entropy_scratch(ctx, 1, mcus, worst, sc))) return rc;
     int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
     launch_fdct_quant(ctx->stream, d_rgb_stripe, 1, width, stripe_height, to_float_tables(lum_q, chr_q), d_coefs,
-                      ctx->d_status);
+                      ctx->d_status, (uint8_t*)ctx->masks.ptr);
     JEA_HIP(ctx, hipGetLastError());
     for (int ch = 0; ch < 3; ++ch)
         JEA_HIP(ctx, hipMemcpyAsync(&last_dc[ch], d_coefs + ((mcus - 1) * 3 + ch) * 64, sizeof(int16_t),
@@ -633,6 +639,7 @@ int jea_stripe_bits(jea_ctx* ctx, const int16_t prev_dc[3], uint64_t* total_bits
     int rc;
     if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc))) return rc;
     if ((rc = ensure(ctx, ctx->small, 256))) return rc;
+    sc.chunk_masks = (const uint8_t*)ctx->masks.ptr;
     StripeInfo st;
     for (int i = 0; i < 3; ++i) st.initial_dc[i] = prev_dc[i];
     uint32_t* d_head = (uint32_t*)ctx->small.ptr;

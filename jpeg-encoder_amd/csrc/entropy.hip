@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
                                                                  uint16_t* __restrict__ len16,
                                                                  uint32_t* __restrict__ tile_bits,
                                                                  uint32_t* __restrict__ slots,
-                                                                 int32_t* __restrict__ status, StripeInfo st) {
+                                                                 int32_t* __restrict__ status, StripeInfo st,
+                                                                 const uint8_t* __restrict__ chunk_masks) {
     __shared__ HuffLds h;
     __shared__ uint32_t wsum[4];
     load_huff(h, huff);
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
     if (threadIdx.x < kTileBlocks && b < nbc) {
         const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
         BlockRegs blk;
-        load_block(blk, p);
+        load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
         const int ch = (int)(b % 3u);
         // same channel, previous MCU; the chain starts at 0 (encoder.cpp:20) or, in a
         // stripe, at the last MCU of the stripe above
@@ -508,7 +509,7 @@ void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, 
     const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
     block_bits_kernel<false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
-        d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status, StripeInfo{});
+        d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status, StripeInfo{}, nullptr);
 }
 
 void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -522,7 +523,7 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const uint32_t eoi = with_eoi ? 1u : 0u;
 
     block_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                         sc.slots, d_status, StripeInfo{});
+                                                         sc.slots, d_status, StripeInfo{}, sc.chunk_masks);
 
     if (n == 1 && n_tiles <= kFoldTiles) {
         // One image with few tiles: every workgroup sums the totals of the tiles
@@ -578,7 +579,7 @@ void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, cons
     const uint32_t nbc = (uint32_t)(mcus * 3);
     const uint32_t n_tiles = tiles_per_image(mcus);
     block_bits_kernel<true><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                                     sc.slots, d_status, st);
+                                                                     sc.slots, d_status, st, sc.chunk_masks);
     ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
     scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
     stripe_head_kernel<<<1, 64, 0, s>>>(sc.len16, sc.slots, nbc, d_head);

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
                                                                   int height, int blocks_w, uint32_t n_mcu,
                                                                   size_t image_bytes, QuantTables q,
                                                                   int16_t* __restrict__ coefs,
-                                                                  int32_t* __restrict__ status_to_clear) {
+                                                                  int32_t* __restrict__ status_to_clear,
+                                                                  uint8_t* __restrict__ chunk_masks) {
     // First kernel of an encode pass: clears the pass's status word so that no
     // separate memset launch is needed (later kernels only ever raise it).
     if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status_to_clear = 0;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
             quantise_col(o, qt, rqt, u, qv);
         }
         // zig-zag (entropy_encoder.cpp:15-77) and hand-over through LDS
+        uint32_t mask = 0;
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) {
             uint4 chunk;
@@ -140,8 +142,10 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
             chunk.y = pack16(qv[kZigzag[8 * k8 + 2]], qv[kZigzag[8 * k8 + 3]]);
             chunk.z = pack16(qv[kZigzag[8 * k8 + 4]], qv[kZigzag[8 * k8 + 5]]);
             chunk.w = pack16(qv[kZigzag[8 * k8 + 6]], qv[kZigzag[8 * k8 + 7]]);
+            mask |= ((chunk.x | chunk.y | chunk.z | chunk.w) != 0 ? 1u : 0u) << k8;
             *reinterpret_cast<uint4*>(lds_out + j * 128 + ((((uint32_t)k8 + j) & 7u) << 4)) = chunk;
         }
+        if (chunk_masks != nullptr) chunk_masks[((size_t)blockIdx.y * n_mcu + g0) * 3 + j] = (uint8_t)mask;
     }
     __syncthreads();
 
@@ -164,7 +168,8 @@ template <bool kFast>
 __global__ __launch_bounds__(64) void fdct_quant_wave_kernel(const uint8_t* __restrict__ rgb, int width, int height,
                                                              int blocks_w, uint32_t n_mcu, size_t image_bytes,
                                                              QuantTables q, int16_t* __restrict__ coefs,
-                                                             int32_t* __restrict__ status_to_clear) {
+                                                             int32_t* __restrict__ status_to_clear,
+                                                             uint8_t* __restrict__ chunk_masks) {
     if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
         *status_to_clear = 0;
     const int channel = blockIdx.y;
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(64) void fdct_quant_wave_kernel(const uint8_t* __re
         quantise_col(o, qt, rqt, u, qv);
     }
     uint4* out = reinterpret_cast<uint4*>(coefs + (((size_t)blockIdx.z * n_mcu + mcu) * 3 + channel) * 64);
+    uint32_t mask = 0;
 #pragma unroll
     for (int k8 = 0; k8 < 8; ++k8) {
         uint4 chunk;
@@ -231,8 +237,10 @@ __global__ __launch_bounds__(64) void fdct_quant_wave_kernel(const uint8_t* __re
         chunk.y = pack16(qv[kZigzag[8 * k8 + 2]], qv[kZigzag[8 * k8 + 3]]);
         chunk.z = pack16(qv[kZigzag[8 * k8 + 4]], qv[kZigzag[8 * k8 + 5]]);
         chunk.w = pack16(qv[kZigzag[8 * k8 + 6]], qv[kZigzag[8 * k8 + 7]]);
+        mask |= ((chunk.x | chunk.y | chunk.z | chunk.w) != 0 ? 1u : 0u) << k8;
         out[k8] = chunk;
     }
+    if (chunk_masks != nullptr) chunk_masks[((size_t)blockIdx.z * n_mcu + mcu) * 3 + channel] = (uint8_t)mask;
 }
 
 // ---------------------------------------------------------------------------
@@ -354,7 +362,7 @@ __global__ void ycbcr_to_rgb_kernel(const uint8_t* __restrict__ ycc, size_t n, u
 }  // namespace
 
 void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
-                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear) {
+                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear, uint8_t* d_chunk_masks) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
@@ -364,18 +372,18 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
     const dim3 wgrid((n_mcu + 63) / 64, 3, (unsigned)n_images);
     if (fast)
         fdct_quant_wave_kernel<true><<<wgrid, 64, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                          d_status_to_clear);
+                                                          d_status_to_clear, d_chunk_masks);
     else
         fdct_quant_wave_kernel<false><<<wgrid, 64, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                           d_status_to_clear);
+                                                           d_status_to_clear, d_chunk_masks);
     return;
 #endif
     if (fast)
         fdct_quant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                              d_status_to_clear);
+                                                              d_status_to_clear, d_chunk_masks);
     else
         fdct_quant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                               d_status_to_clear);
+                                                               d_status_to_clear, d_chunk_masks);
 }
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,

@@ -27,11 +27,13 @@ struct BlockRegs {
     __device__ __forceinline__ int at(int k) const { return (int)(int16_t)(w[k >> 1] >> (16 * (k & 1))); }
 };
 
-__device__ __forceinline__ void load_block(BlockRegs& r, const int16_t* __restrict__ p) {
+// `chunk_mask` bit i clear = the i-th 16-byte chunk is known to be all zero and is not read.
+__device__ __forceinline__ void load_block(BlockRegs& r, const int16_t* __restrict__ p, uint32_t chunk_mask = 0xffu) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint4 v = q[i];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((chunk_mask >> i) & 1u) v = q[i];
         r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
     }
 }
