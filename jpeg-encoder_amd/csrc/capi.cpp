@@ -42,6 +42,9 @@ struct jea_ctx {
     DeviceBuffer coefs, masks, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
     DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
     DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
+    // parallel decode
+    DeviceBuffer seg_ubase, ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
+        round_flags;
     size_t stream_len = 0;
     // stripe encode in progress (jea_stripe_*)
     size_t stripe_mcus = 0;
@@ -271,7 +274,10 @@ void jea_destroy(jea_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (DeviceBuffer* b : {&ctx->coefs, &ctx->masks, &ctx->len16, &ctx->slots, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
                             &ctx->tile_ffbase, &ctx->img_words, &ctx->unstuffed, &ctx->stage_in, &ctx->stage_out,
-                            &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small})
+                            &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small,
+                            &ctx->seg_ubase, &ctx->ustream, &ctx->chunk_drops, &ctx->chunk_base, &ctx->img_drops,
+                            &ctx->sub_end, &ctx->sub_used, &ctx->sub_info, &ctx->grp_sum, &ctx->grp_base,
+                            &ctx->round_flags})
         free_buffer(*b);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_decode) (void)hipFree(ctx->d_decode);
@@ -693,21 +699,55 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
 
 // ---- decode -------------------------------------------------------------------
 
-static int upload_segments(jea_ctx* ctx, const uint64_t* h_offsets, const uint64_t* h_sizes, size_t n_images,
-                           uint64_t skip) {
-    int rc;
-    if ((rc = ensure(ctx, ctx->seg_offsets, n_images * sizeof(uint64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->seg_sizes, n_images * sizeof(uint64_t)))) return rc;
-    std::vector<uint64_t> off(n_images), sz(n_images);
+// Uploads the scan ranges (file ranges minus `skip` leading header bytes), sizes the
+// scratch of the parallel decoder and runs it.  Leaves the device status unread.
+static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_t* h_offsets, const uint64_t* h_sizes,
+                              size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs) {
+    std::vector<uint64_t> seg(3 * n_images);   // offsets | sizes | unstuffed bases
+    uint64_t max_size = 0, ubytes = 0;
     for (size_t i = 0; i < n_images; ++i) {
         if (h_sizes[i] < skip + 2) return fail(ctx, JEA_ERR_NO_EOI, "Failed to find EOI marker");
-        off[i] = h_offsets[i] + skip;
-        sz[i] = h_sizes[i] - skip;
+        seg[i] = h_offsets[i] + skip;
+        seg[n_images + i] = h_sizes[i] - skip;
+        seg[2 * n_images + i] = ubytes;
+        ubytes += (h_sizes[i] - skip + 15) / 16 * 16 + 16;
+        if (h_sizes[i] - skip > max_size) max_size = h_sizes[i] - skip;
     }
-    // the vectors die at return: use the blocking copy
+    if (mcus * 3 > 0x7fffffffull || max_size * 8 / (32 * kDecodeSubWords) > 0x7fffffffull)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "decode: image or stream too large");
+    const DecodePlan plan = plan_entropy_decode(n_images, max_size, mcus);
+    const size_t subs = (size_t)plan.n_groups * 256;
+    int rc;
+    if ((rc = ensure(ctx, ctx->seg_offsets, 3 * n_images * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ustream, ubytes))) return rc;
+    if ((rc = ensure(ctx, ctx->chunk_drops, n_images * plan.n_chunks * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->chunk_base, n_images * plan.n_chunks * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->img_drops, n_images * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_end, n_images * subs * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_used, n_images * subs * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_info, n_images * subs * sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->grp_sum, n_images * plan.n_groups * sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->grp_base, n_images * plan.n_groups * sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->round_flags, 4 * sizeof(uint32_t)))) return rc;
+    // the vector dies at return: use the blocking copy
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    JEA_HIP(ctx, hipMemcpy(ctx->seg_offsets.ptr, off.data(), n_images * sizeof(uint64_t), hipMemcpyHostToDevice));
-    JEA_HIP(ctx, hipMemcpy(ctx->seg_sizes.ptr, sz.data(), n_images * sizeof(uint64_t), hipMemcpyHostToDevice));
+    JEA_HIP(ctx, hipMemcpy(ctx->seg_offsets.ptr, seg.data(), seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const uint64_t* d_seg = (const uint64_t*)ctx->seg_offsets.ptr;
+    DecodeScratch sc;
+    sc.ubase = d_seg + 2 * n_images;
+    sc.ustream = (uint8_t*)ctx->ustream.ptr;
+    sc.chunk_drops = (uint32_t*)ctx->chunk_drops.ptr;
+    sc.chunk_base = (uint64_t*)ctx->chunk_base.ptr;
+    sc.img_drops = (uint64_t*)ctx->img_drops.ptr;
+    sc.sub_end = (uint32_t*)ctx->sub_end.ptr;
+    sc.sub_used = (uint32_t*)ctx->sub_used.ptr;
+    sc.sub_info = (int4*)ctx->sub_info.ptr;
+    sc.grp_sum = (int4*)ctx->grp_sum.ptr;
+    sc.grp_base = (int4*)ctx->grp_base.ptr;
+    sc.changed = (uint32_t*)ctx->round_flags.ptr;
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs,
+                                       ctx->d_status));
     return JEA_OK;
 }
 
@@ -717,13 +757,9 @@ int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_of
     if (!d_scan || !h_offsets || !h_sizes || !d_coefs || n_images == 0 || mcus_per_image == 0)
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_entropy_decode: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = upload_segments(ctx, h_offsets, h_sizes, n_images, 0);
+    if (n_images > 65535) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_entropy_decode: more than 65535 images");
+    int rc = run_entropy_decode(ctx, d_scan, h_offsets, h_sizes, n_images, 0, mcus_per_image, d_coefs);
     if (rc) return rc;
-    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
-    launch_entropy_decode(ctx->stream, d_scan, (const uint64_t*)ctx->seg_offsets.ptr,
-                          (const uint64_t*)ctx->seg_sizes.ptr, n_images, mcus_per_image, ctx->d_decode, d_coefs,
-                          ctx->d_status);
-    JEA_HIP(ctx, hipGetLastError());
     return finish_status(ctx, ctx->d_status, "jea_entropy_decode");
 }
 
@@ -749,12 +785,9 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     const size_t mcus = mcus_of(width, height);
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
-    if ((rc = upload_segments(ctx, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES))) return rc;
-    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
-    launch_entropy_decode(ctx->stream, d_jpeg, (const uint64_t*)ctx->seg_offsets.ptr,
-                          (const uint64_t*)ctx->seg_sizes.ptr, n_images, mcus, ctx->d_decode,
-                          (int16_t*)ctx->coefs.ptr, ctx->d_status);
-    JEA_HIP(ctx, hipGetLastError());
+    if ((rc = run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,
+                                 (int16_t*)ctx->coefs.ptr)))
+        return rc;
     // As in the reference, nothing is written to the output when the stream is bad (encoder.cpp:63-70).
     if ((rc = finish_status(ctx, ctx->d_status, "jea_decode_batch"))) return rc;
     launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height,

@@ -1,0 +1,587 @@
+// Parallel Huffman decode of reference-format scans for gfx950.
+//
+// The reference reads one image's scan bit by bit from a single serial
+// BitStream (jpeg/src/encoder.cpp:46-60, jpeg/src/entropy_encoder.cpp:703-712,
+// 767-866); the stream has no restart markers (encoder.cpp:121-137), so nothing
+// in the file says where a block starts.  Here the same coefficients are
+// produced by many threads per image:
+//
+//   unstuff_count_kernel / scan_tiles / unstuff_compact_kernel
+//       remove the stuffed bytes exactly as BitStream::removeStuffedBytes does
+//       (bit_stream.cpp:136-147: a 0x00 that follows a 0xFF located before the
+//       last two bytes of the stream is dropped), into a word-aligned copy
+//   decode_sync_kernel (repeated until nothing changes)
+//       the unstuffed stream is cut into sub-sequences of kSubBits bits, one per
+//       thread.  A decoder state is (bit position, colour channel, zig-zag
+//       progress inside the block).  Every thread first decodes its sub-sequence
+//       from a guessed state; Huffman streams re-synchronise after a few
+//       symbols, so its END state is usually right even when the guess was not.
+//       Then each thread whose predecessor's end state differs from the state it
+//       started from decodes again from that state, until no thread had to: at
+//       that fixed point every sub-sequence has been decoded from the state the
+//       serial decoder would have been in.  Each decode also counts the blocks
+//       it completes and sums the DC differences it meets per channel.
+//   scan_groups_kernel
+//       exclusive scan of those counts and sums over the workgroups of an image
+//   decode_write_kernel
+//       one more decode from the now known states, this time with the block
+//       index and the running DC of each channel known at the start of every
+//       sub-sequence, storing the non-zero coefficients into the zeroed output
+//
+// Run-length removal follows entropy_encoder.cpp:122-144 including its quirk:
+// the last run-length entry of a block is never restored, so a block whose
+// entries fill all 63 AC positions loses the final one.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "../../include/jpegenc_amd.h"
+
+namespace jea {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kChunkBytes = 4096;            // raw bytes per workgroup of the unstuffing passes
+constexpr uint32_t kSubWords = kDecodeSubWords;   // 32-bit words per sub-sequence
+constexpr uint32_t kSubBits = 32 * kSubWords;
+constexpr uint32_t kGroupWords = kThreads * kSubWords;
+constexpr uint32_t kNoState = 0xffffffffu;
+static_assert(kSubBits >= 64, "a symbol (27 bits at most) must fit well inside a sub-sequence");
+
+// state word: bits 0-7 bit offset past the sub-sequence start, 8-9 channel, 16-21 zig-zag progress
+__device__ __forceinline__ uint32_t make_state(uint32_t ovf, uint32_t c, uint32_t z) { return ovf | (c << 8) | (z << 16); }
+
+struct Sums {
+    int nb, dc0, dc1, dc2;
+};
+__device__ __forceinline__ Sums operator+(Sums a, Sums b) { return {a.nb + b.nb, a.dc0 + b.dc0, a.dc1 + b.dc1, a.dc2 + b.dc2}; }
+
+__device__ __forceinline__ Sums shfl_up(Sums v, int d) {
+    return {__shfl_up(v.nb, d), __shfl_up(v.dc0, d), __shfl_up(v.dc1, d), __shfl_up(v.dc2, d)};
+}
+
+// Exclusive scan over the 256 threads of a workgroup; `total` gets the sum.
+__device__ __forceinline__ Sums block_exclusive_scan(Sums v, Sums* lds4, Sums& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Sums incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const Sums t = shfl_up(incl, d);
+        if (lane >= d) incl = incl + t;
+    }
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    Sums base{0, 0, 0, 0};
+    for (int w = 0; w < wave; ++w) base = base + lds4[w];
+    total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return {base.nb + incl.nb - v.nb, base.dc0 + incl.dc0 - v.dc0, base.dc1 + incl.dc1 - v.dc1,
+            base.dc2 + incl.dc2 - v.dc2};
+}
+
+// ---------------------------------------------------------------------------
+// Unstuffing
+// ---------------------------------------------------------------------------
+
+// Bit k of the result is set when raw byte j0 + k is a stuffed zero.
+__device__ __forceinline__ uint32_t drop_mask16(const uint8_t* __restrict__ file, uint64_t len, uint64_t scan_end,
+                                                uint64_t j0, uint8_t* bytes) {
+    uint32_t prev = (j0 >= 1 && j0 - 1 < len) ? file[j0 - 1] : 0u;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint64_t j = j0 + k;
+        const uint32_t b = j < len ? file[j] : 0x01u;
+        bytes[k] = (uint8_t)b;
+        // bit_stream.cpp:137-138: only a 0xFF before the last two bytes makes the next zero vanish
+        if (j < len && b == 0u && prev == 0xFFu && j - 1 < scan_end) mask |= 1u << k;
+        prev = b;
+    }
+    return mask;
+}
+
+__global__ __launch_bounds__(kThreads) void unstuff_count_kernel(const uint8_t* __restrict__ scan,
+                                                                 const uint64_t* __restrict__ offsets,
+                                                                 const uint64_t* __restrict__ sizes,
+                                                                 uint32_t n_chunks,
+                                                                 uint32_t* __restrict__ chunk_drops) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t chunk = blockIdx.x, img = blockIdx.y;
+    const uint64_t len = sizes[img];
+    const uint64_t j0 = (uint64_t)chunk * kChunkBytes + 16u * threadIdx.x;
+    uint32_t n = 0;
+    if (j0 < len) {
+        uint8_t bytes[16];
+        n = __popc(drop_mask16(scan + offsets[img], len, len >= 2 ? len - 2 : 0, j0, bytes));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_drops[(size_t)img * n_chunks + chunk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t* __restrict__ scan,
+                                                                   const uint64_t* __restrict__ offsets,
+                                                                   const uint64_t* __restrict__ sizes,
+                                                                   uint32_t n_chunks,
+                                                                   const uint64_t* __restrict__ chunk_base,
+                                                                   const uint64_t* __restrict__ ubase,
+                                                                   uint8_t* __restrict__ ustream) {
+    __shared__ uint8_t kept[kChunkBytes];
+    __shared__ uint32_t wsum[4];
+    const uint32_t chunk = blockIdx.x, img = blockIdx.y;
+    const uint64_t len = sizes[img];
+    const uint64_t c0 = (uint64_t)chunk * kChunkBytes;
+    if (c0 >= len) return;
+    const uint64_t j0 = c0 + 16u * threadIdx.x;
+    uint8_t bytes[16];
+    uint32_t mask = 0, valid = 0;
+    if (j0 < len) {
+        mask = drop_mask16(scan + offsets[img], len, len >= 2 ? len - 2 : 0, j0, bytes);
+        valid = (uint32_t)((len - j0 < 16) ? len - j0 : 16);
+    }
+    const uint32_t drops = __popc(mask);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = drops;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - drops;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    const uint32_t total_drops = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint32_t o = 16u * threadIdx.x - before;
+    for (uint32_t k = 0; k < valid; ++k)
+        if (!((mask >> k) & 1u)) kept[o++] = bytes[k];
+    __syncthreads();
+    const uint32_t in_chunk = (uint32_t)((len - c0 < kChunkBytes) ? len - c0 : kChunkBytes);
+    const uint32_t n_kept = in_chunk - total_drops;
+    uint8_t* dst = ustream + ubase[img] + c0 - chunk_base[(size_t)img * n_chunks + chunk];
+    for (uint32_t i = threadIdx.x; i < n_kept; i += kThreads) dst[i] = kept[i];
+}
+
+// ---------------------------------------------------------------------------
+// Sub-sequence decoding
+// ---------------------------------------------------------------------------
+
+// The words of one workgroup's 256 sub-sequences plus one more word, MSB-first
+// values, padded by one word per sub-sequence so that threads reading the same
+// word of their own sub-sequences hit different LDS banks.
+struct GroupWords {
+    uint32_t w[(kThreads + 1) * (kSubWords + 1)];
+    __device__ __forceinline__ uint32_t at(uint32_t wi) const { return w[wi + wi / kSubWords]; }
+};
+
+__device__ __forceinline__ void stage_group(GroupWords& gw, const uint8_t* __restrict__ stream, uint64_t ulen,
+                                            uint32_t group) {
+    const uint64_t first_word = (uint64_t)group * kGroupWords;
+    for (uint32_t i = threadIdx.x; i < kGroupWords + 1; i += kThreads) {
+        const uint64_t byte = (first_word + i) * 4;
+        uint32_t v = 0;
+        if (byte + 4 <= ulen) {
+            v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(stream + byte));
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (byte + k < ulen) v |= (uint32_t)stream[byte + k] << (24 - 8 * k);
+        }
+        gw.w[i + i / kSubWords] = v;
+    }
+}
+
+// Canonical decode of the code word at the top of v: 9-bit table, then the
+// max-code-per-length walk (T.81 F.2.2.3), which is what growing a candidate
+// code bit by bit until it equals a code word (entropy_encoder.cpp:767-778,
+// 810-828) amounts to for these prefix codes.  len = 0: no code word matches.
+__device__ __forceinline__ void huff_lookup(const DecodeTable& t, uint32_t v, uint32_t& len, uint32_t& sym) {
+    const uint32_t e = t.fast[v >> 23];
+    if (e) {
+        len = e >> 8;
+        sym = e & 0xffu;
+        return;
+    }
+    const uint32_t p16 = v >> 16;
+    len = 0;
+    sym = 0;
+    for (uint32_t l = 10; l <= 16; ++l) {
+        const int code = (int)(p16 >> (16 - l));
+        if (code <= t.maxcode[l]) {
+            len = l;
+            sym = t.vals[(code + t.valoff[l]) & 255];
+            return;
+        }
+    }
+}
+
+// entropy_encoder.cpp:786-806, 845-864
+__device__ __forceinline__ int amplitude(uint32_t v, uint32_t len, uint32_t ssss) {
+    const uint32_t bits = (v << len) >> (32 - ssss);
+    const uint32_t mask = (1u << ssss) - 1u;
+    if (bits >> (ssss - 1)) return (int)bits;
+    return -(int)(mask & ~bits);
+}
+
+struct WriteTarget {
+    int16_t* out;            // coefficients of this image
+    uint32_t block;          // index of the block the start state is in
+    uint32_t total_blocks;
+    int last[3];             // running DC per channel at the start state
+    bool error;              // a malformed symbol was met before the last block ended
+    bool finished;           // this walk completed the image's last block ...
+    uint32_t final_bit;      // ... at this bit position (relative to the group)
+};
+
+// Decode from `state` (of sub-sequence `sub` of the staged group) to the first
+// symbol boundary at or past the end of the sub-sequence.  Malformed symbols do
+// not stop the walk (one bit is skipped), so that a walk from a wrong guess
+// always ends; on the true chain they are reported through WriteTarget::error.
+template <bool kWrite>
+__device__ __forceinline__ uint32_t walk(const GroupWords& gw, const DecodeTables& t, uint32_t sub, uint32_t state,
+                                         Sums& sums, WriteTarget* wt) {
+    uint32_t p = sub * kSubBits + (state & 0xffu);
+    uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
+    const uint32_t end = (sub + 1) * kSubBits;
+    int nb = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    uint32_t wi = p >> 5;
+    uint32_t hi = gw.at(wi), lo = gw.at(wi + 1);
+    while (p < end) {
+        if ((p >> 5) != wi) {
+            wi = p >> 5;
+            hi = gw.at(wi);
+            lo = gw.at(wi + 1);
+        }
+        const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) << (p & 31u) >> 32);
+        uint32_t len, sym;
+        bool block_done = false;
+        if (z == 0) {
+            huff_lookup(t.tab[c ? 2 : 0], v, len, sym);
+            if (len == 0 || sym > 11) {
+                if (kWrite) wt->error = true;
+                p += 1;
+                continue;
+            }
+            const int diff = sym ? amplitude(v, len, sym) : 0;
+            p += len + sym;
+            dc0 += (c == 0) ? diff : 0;
+            dc1 += (c == 1) ? diff : 0;
+            dc2 += (c == 2) ? diff : 0;
+            if (kWrite) {
+                // entropy_encoder.cpp:125-126: the DC chain runs in int16
+                const int dc = (int)(int16_t)(wt->last[c] + diff);
+                wt->last[c] = dc;
+                if (dc != 0) wt->out[(size_t)wt->block * 64] = (int16_t)dc;
+            }
+            z = 1;
+        } else {
+            huff_lookup(t.tab[c ? 3 : 1], v, len, sym);
+            const uint32_t ss = sym & 15u;
+            if (len == 0 || (ss == 0 && sym != 0x00 && sym != 0xF0) || ss > 10) {
+                if (kWrite) wt->error = true;
+                p += 1;
+                continue;
+            }
+            p += len + ss;
+            if (sym == 0x00) {
+                block_done = true;                     // EOB
+            } else {
+                const uint32_t processed = z + (sym >> 4);   // AC positions consumed including this entry
+                if (processed >= 63) {
+                    // == 63: the block is full and this entry, being the last, is dropped
+                    // (entropy_encoder.cpp:129); > 63 is a stream error for the serial decoder
+                    if (kWrite && processed > 63) wt->error = true;
+                    block_done = true;
+                } else {
+                    if (kWrite && ss) wt->out[(size_t)wt->block * 64 + processed] = (int16_t)amplitude(v, len, ss);
+                    z = processed + 1;
+                }
+            }
+        }
+        if (block_done) {
+            z = 0;
+            c = (c == 2) ? 0 : c + 1;
+            ++nb;
+            if (kWrite) {
+                if (++wt->block == wt->total_blocks) {
+                    wt->finished = true;
+                    wt->final_bit = p;
+                    break;
+                }
+            }
+        }
+    }
+    sums = Sums{nb, dc0, dc1, dc2};
+    return make_state(p >= end ? p - end : 0, c, z);
+}
+
+__global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __restrict__ ustream,
+                                                               const uint64_t* __restrict__ ubase,
+                                                               const uint64_t* __restrict__ sizes,
+                                                               const uint64_t* __restrict__ img_drops,
+                                                               uint32_t n_groups, int first_round,
+                                                               const DecodeTables* __restrict__ tables,
+                                                               uint32_t* __restrict__ sub_end,
+                                                               uint32_t* __restrict__ sub_used,
+                                                               int4* __restrict__ sub_info,
+                                                               int4* __restrict__ grp_sum,
+                                                               uint32_t* __restrict__ changed) {
+    __shared__ GroupWords gw;
+    __shared__ DecodeTables t;
+    __shared__ uint32_t ends[kThreads + 1];   // ends[i] = state at the start of sub-sequence i
+    __shared__ Sums red[4];
+
+    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const uint64_t ulen = sizes[img] - img_drops[img];
+    const uint64_t total_bits = 8 * ulen;
+    const size_t sub_index = ((size_t)img * n_groups + group) * kThreads + tid;
+    const uint64_t first_bit = ((uint64_t)group * kThreads + tid) * kSubBits;
+    if ((uint64_t)group * kThreads * kSubBits >= total_bits) {   // nothing of the stream in this group
+        if (first_round && tid == 0) grp_sum[(size_t)img * n_groups + group] = make_int4(0, 0, 0, 0);
+        return;
+    }
+    const bool active = first_bit < total_bits;
+
+    for (uint32_t i = tid; i < sizeof(DecodeTables) / 4; i += kThreads)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
+    stage_group(gw, ustream + ubase[img], ulen, group);
+
+    uint32_t used = kNoState, my_end = 0;
+    Sums sums{0, 0, 0, 0};
+    if (!first_round) {
+        my_end = sub_end[sub_index];
+        used = sub_used[sub_index];
+        const int4 s = sub_info[sub_index];
+        sums = Sums{s.x, s.y, s.z, s.w};
+    }
+    ends[tid + 1] = my_end;
+    if (tid == 0) {
+        // the image starts in state 0; a later group starts where the previous one ended, which in
+        // the first round is not known yet and guessed as state 0
+        uint32_t entry = 0;
+        if (group > 0 && !first_round)
+            entry = __atomic_load_n(&sub_end[sub_index - 1], __ATOMIC_RELAXED);
+        ends[0] = entry;
+    }
+    __syncthreads();
+
+    bool dirty = false;
+    for (;;) {
+        const uint32_t start = ends[tid];
+        const bool redo = active && start != used;
+        if (redo) {
+            my_end = walk<false>(gw, t, tid, start, sums, nullptr);
+            used = start;
+            dirty = true;
+        }
+        __syncthreads();
+        if (redo) ends[tid + 1] = my_end;
+        if (!__syncthreads_or(redo ? 1 : 0)) break;
+    }
+
+    const int any_dirty = __syncthreads_or(dirty ? 1 : 0);
+    if (dirty) {
+        __atomic_store_n(&sub_end[sub_index], my_end, __ATOMIC_RELAXED);
+        sub_used[sub_index] = used;
+        sub_info[sub_index] = make_int4(sums.nb, sums.dc0, sums.dc1, sums.dc2);
+    } else if (first_round) {   // sub-sequences past the end of the stream
+        sub_end[sub_index] = 0;
+        sub_used[sub_index] = kNoState;
+        sub_info[sub_index] = make_int4(0, 0, 0, 0);
+    }
+    if (any_dirty || first_round) {
+        Sums v = sums;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            v = v + Sums{__shfl_xor(v.nb, d), __shfl_xor(v.dc0, d), __shfl_xor(v.dc1, d), __shfl_xor(v.dc2, d)};
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            const Sums s = red[0] + red[1] + red[2] + red[3];
+            grp_sum[(size_t)img * n_groups + group] = make_int4(s.nb, s.dc0, s.dc1, s.dc2);
+            if (any_dirty) atomicOr(changed, 1u);
+        }
+    }
+}
+
+// One workgroup per image: exclusive scan of the group sums; an image whose
+// stream holds fewer blocks than the picture needs is a stream error (the serial
+// decoder would run off the end of the file).
+__global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __restrict__ grp_sum, uint32_t n_groups,
+                                                               uint32_t total_blocks, int4* __restrict__ grp_base,
+                                                               int32_t* __restrict__ status) {
+    __shared__ Sums lds4[4];
+    __shared__ Sums carry_s;
+    const uint32_t img = blockIdx.x;
+    if (threadIdx.x == 0) carry_s = Sums{0, 0, 0, 0};
+    __syncthreads();
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += kThreads) {
+        const uint32_t g = g0 + threadIdx.x;
+        Sums v{0, 0, 0, 0};
+        if (g < n_groups) {
+            const int4 s = grp_sum[(size_t)img * n_groups + g];
+            v = Sums{s.x, s.y, s.z, s.w};
+        }
+        Sums total;
+        const Sums excl = block_exclusive_scan(v, lds4, total);
+        const Sums base = carry_s + excl;
+        if (g < n_groups) grp_base[(size_t)img * n_groups + g] = make_int4(base.nb, base.dc0, base.dc1, base.dc2);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry_s + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && (uint32_t)carry_s.nb < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
+}
+
+__global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* __restrict__ ustream,
+                                                                const uint64_t* __restrict__ ubase,
+                                                                const uint64_t* __restrict__ sizes,
+                                                                const uint64_t* __restrict__ img_drops,
+                                                                uint32_t n_groups, uint32_t total_blocks,
+                                                                const DecodeTables* __restrict__ tables,
+                                                                const uint32_t* __restrict__ sub_used,
+                                                                const int4* __restrict__ sub_info,
+                                                                const int4* __restrict__ grp_base,
+                                                                int16_t* __restrict__ coefs,
+                                                                int32_t* __restrict__ status) {
+    __shared__ GroupWords gw;
+    __shared__ DecodeTables t;
+    __shared__ Sums lds4[4];
+
+    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const uint64_t ulen = sizes[img] - img_drops[img];
+    const uint64_t total_bits = 8 * ulen;
+    if ((uint64_t)group * kThreads * kSubBits >= total_bits) return;
+    const int4 gb = grp_base[(size_t)img * n_groups + group];
+    if ((uint32_t)gb.x >= total_blocks) return;   // the picture is complete before this group
+    const size_t sub_index = ((size_t)img * n_groups + group) * kThreads + tid;
+    const uint64_t first_bit = ((uint64_t)group * kThreads + tid) * kSubBits;
+    const bool active = first_bit < total_bits;
+
+    for (uint32_t i = tid; i < sizeof(DecodeTables) / 4; i += kThreads)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
+    const uint8_t* stream = ustream + ubase[img];
+    stage_group(gw, stream, ulen, group);
+
+    const int4 si = sub_info[sub_index];
+    Sums total;
+    const Sums before = block_exclusive_scan(Sums{si.x, si.y, si.z, si.w}, lds4, total);   // also orders the staging
+    WriteTarget wt;
+    wt.out = coefs + (size_t)img * total_blocks * 64;
+    wt.block = (uint32_t)(gb.x + before.nb);
+    wt.total_blocks = total_blocks;
+    wt.last[0] = (int)(int16_t)(gb.y + before.dc0);
+    wt.last[1] = (int)(int16_t)(gb.z + before.dc1);
+    wt.last[2] = (int)(int16_t)(gb.w + before.dc2);
+    wt.error = false;
+    wt.finished = false;
+    wt.final_bit = 0;
+    if (!active || wt.block >= total_blocks) return;
+
+    Sums sums;
+    (void)walk<true>(gw, t, tid, sub_used[sub_index], sums, &wt);
+    if (wt.error) {
+        // a malformed symbol outranks a missing end marker, as in the serial order of checks
+        const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
+        if (old == JEA_ERR_NO_EOI) atomicCAS(status, JEA_ERR_NO_EOI, JEA_ERR_BAD_STREAM);
+    }
+    if (wt.finished) {
+        const uint64_t end_bit = (uint64_t)group * kThreads * kSubBits + wt.final_bit;
+        if (end_bit > total_bits) {   // bits past the end of the file were consumed
+            const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
+            if (old == JEA_ERR_NO_EOI) atomicCAS(status, JEA_ERR_NO_EOI, JEA_ERR_BAD_STREAM);
+        } else {
+            // encoder.cpp:62-65: skip to the byte boundary, the next two bytes must be the EOI marker
+            const uint64_t q = (end_bit + 7) >> 3;
+            if (q + 2 > ulen || stream[q] != 0xFFu || stream[q + 1] != 0xD9u) atomicCAS(status, 0, JEA_ERR_NO_EOI);
+        }
+    }
+}
+
+// Same exclusive scan as the encoder's per-image tile scan, for the chunk drop counts.
+__global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t* __restrict__ in, uint32_t n,
+                                                           uint64_t* __restrict__ out,
+                                                           uint64_t* __restrict__ img_total) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t img = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint64_t v = (t < n) ? (uint64_t)in[(size_t)img * n + t] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t u = __shfl_up(incl, d);
+            if (lane >= d) incl += u;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint64_t base = carry_s;
+        for (int w = 0; w < wave; ++w) base += wave_sum[w];
+        if (t < n) out[(size_t)img * n + t] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) img_total[img] = carry_s;
+}
+
+}  // namespace
+
+DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image) {
+    DecodePlan p;
+    p.n_images = (uint32_t)n_images;
+    p.n_chunks = (uint32_t)((max_scan_bytes + kChunkBytes - 1) / kChunkBytes);
+    const uint64_t subs = ((uint64_t)max_scan_bytes * 8 + kSubBits - 1) / kSubBits;
+    p.n_groups = (uint32_t)((subs + kThreads - 1) / kThreads);
+    if (p.n_chunks == 0) p.n_chunks = 1;
+    if (p.n_groups == 0) p.n_groups = 1;
+    p.total_blocks = (uint32_t)(mcus_per_image * 3);
+    return p;
+}
+
+hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
+                                 const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
+                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status) {
+    hipError_t e;
+    const dim3 cgrid(p.n_chunks, p.n_images), ggrid(p.n_groups, p.n_images);
+    unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops);
+    scan_chunks_kernel<<<p.n_images, 1024, 0, s>>>(sc.chunk_drops, p.n_chunks, sc.chunk_base, sc.img_drops);
+    unstuff_compact_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_base, sc.ubase,
+                                                      sc.ustream);
+    if ((e = hipMemsetAsync(sc.changed, 0, 4 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_coefs, 0, (size_t)p.n_images * p.total_blocks * 64 * sizeof(int16_t), s)) != hipSuccess)
+        return e;
+    // Three rounds up front: the first decodes everything, the second repairs the starts of the
+    // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.
+    for (int r = 0; r < 3; ++r)
+        decode_sync_kernel<<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                      r == 0 ? 1 : 0, d_tables, sc.sub_end, sc.sub_used, sc.sub_info,
+                                                      sc.grp_sum, sc.changed + r);
+    uint32_t changed = 0;
+    if ((e = hipMemcpyAsync(&changed, sc.changed + 2, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    // Streams that do not re-synchronise within a workgroup's 256 sub-sequences need one more
+    // round per workgroup the error travels through; n_groups rounds always suffice.
+    for (uint32_t extra = 0; changed != 0; ++extra) {
+        if (extra > p.n_groups + 1) return hipErrorUnknown;
+        if ((e = hipMemsetAsync(sc.changed + 3, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
+        decode_sync_kernel<<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, 0,
+                                                      d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
+                                                      sc.changed + 3);
+        if ((e = hipMemcpyAsync(&changed, sc.changed + 3, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess)
+            return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    }
+    scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base, d_status);
+    decode_write_kernel<<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                   p.total_blocks, d_tables, sc.sub_used, sc.sub_info, sc.grp_base,
+                                                   d_coefs, d_status);
+    return hipGetLastError();
+}
+
+}  // namespace jea

@@ -432,76 +432,6 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
     }
 }
 
-// ---------------------------------------------------------------------------
-// Decode: one wave per image; lane 0 walks the serial Huffman chain (the
-// reference stream has no restart markers, encoder.cpp:121-137), the other lanes
-// stage stream bytes into LDS and store finished blocks.
-// ---------------------------------------------------------------------------
-
-__global__ __launch_bounds__(64) void entropy_decode_kernel(const uint8_t* __restrict__ scan,
-                                                            const uint64_t* __restrict__ offsets,
-                                                            const uint64_t* __restrict__ sizes, uint32_t n_mcu,
-                                                            const DecodeTables* __restrict__ tables,
-                                                            int16_t* __restrict__ coefs,
-                                                            int32_t* __restrict__ status) {
-    __shared__ DecodeTables t;
-    __shared__ __align__(16) uint8_t stream[kStreamWin + 16];
-    __shared__ int16_t zz[64];
-    __shared__ uint64_t sh_pos;
-    __shared__ int sh_err;
-
-    const uint32_t img = blockIdx.x, lane = threadIdx.x;
-    const uint8_t* file = scan + offsets[img];
-    const uint64_t len = sizes[img];
-    for (uint32_t i = lane; i < sizeof(DecodeTables) / 4; i += 64)
-        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
-    if (lane == 0) { sh_pos = 0; sh_err = 0; }
-    __syncthreads();
-
-    SerialReader rd{stream, 0, 0, len >= 2 ? len - 2 : 0, len, 0, 0, 0};
-    int last_y = 0, last_cb = 0, last_cr = 0;   // encoder.cpp:51
-    uint64_t win_base = ~0ull;
-    const uint32_t nbc = n_mcu * 3;
-    int16_t* out = coefs + (size_t)img * nbc * 64;
-
-    for (uint32_t b = 0; b < nbc; ++b) {
-        // (re)stage the stream window so that lane 0 has >= 1000 raw bytes ahead:
-        // one block-channel is at most 1660 bits, 416 bytes when fully stuffed
-        const uint64_t pos = sh_pos;
-        if (win_base == ~0ull || pos + 1024 > win_base + kStreamWin) {
-            __syncthreads();
-            win_base = pos;
-            for (uint32_t i = lane; i < kStreamWin + 16; i += 64) stream[i] = (win_base + i < len) ? file[win_base + i] : 0;
-        }
-        zz[lane] = 0;
-        __syncthreads();
-        if (lane == 0 && sh_err == 0) {
-            rd.base = win_base;
-            const int ch = (int)(b % 3u);
-            int last = ch == 0 ? last_y : (ch == 1 ? last_cb : last_cr);
-            const int err = decode_block(rd, t.tab[ch ? 2 : 0], t.tab[ch ? 3 : 1], last, zz);
-            if (ch == 0) last_y = last; else if (ch == 1) last_cb = last; else last_cr = last;
-            // everything before rd.pos - 9 has left the window for good (the bit buffer holds < 9 bytes)
-            sh_pos = rd.pos > 16 ? rd.pos - 16 : 0;
-            if (err) sh_err = err;
-        }
-        __syncthreads();
-        out[(size_t)b * 64 + lane] = zz[lane];
-    }
-    __syncthreads();
-    if (lane == 0) {
-        int err = sh_err;
-        if (!err) {
-            // encoder.cpp:63: byte-align, then the next word must be EOI
-            rd.base = win_base;
-            rd.skip(rd.nbits & 7);
-            rd.refill();
-            if (rd.peek(16) != 0xFFD9u || rd.nbits - 16 < 8 * rd.phantom) err = JEA_ERR_NO_EOI;
-        }
-        if (err) atomicCAS(status, 0, err);
-    }
-}
-
 }  // namespace
 
 void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -602,13 +532,6 @@ void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, 
                                                      sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets,
                                                      d_sizes, header, (uint32_t)header_len, eoi, d_out, out_capacity,
                                                      d_status, st);
-}
-
-void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
-                           size_t n_images, size_t mcus_per_image, const DecodeTables* d_tables, int16_t* d_coefs,
-                           int32_t* d_status) {
-    entropy_decode_kernel<<<(unsigned)n_images, 64, 0, s>>>(d_scan, d_offsets, d_sizes, (uint32_t)mcus_per_image,
-                                                           d_tables, d_coefs, d_status);
 }
 
 }  // namespace jea

@@ -115,9 +115,40 @@ void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, 
                           const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
                           size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
 
-void launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
-                           size_t n_images, size_t mcus_per_image, const DecodeTables* d_tables, int16_t* d_coefs,
-                           int32_t* d_status);
+// Parallel Huffman decode (decode.hip).  The scan of image i is the byte range
+// [d_offsets[i], d_offsets[i] + d_sizes[i]) of d_scan and ends with the EOI marker.
+constexpr uint32_t kDecodeSubWords = 16;  // 32-bit words of unstuffed stream decoded by one thread
+
+struct DecodePlan {
+    uint32_t n_images = 0;
+    uint32_t n_chunks = 0;      // 4096-byte pieces of the longest raw scan
+    uint32_t n_groups = 0;      // workgroups (256 sub-sequences each) covering the longest scan
+    uint32_t total_blocks = 0;  // block-channels per image
+};
+DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image);
+
+// Caller-provided scratch; n = images, subs = n_groups * 256.
+struct DecodeScratch {
+    const uint64_t* ubase;   // [n] byte offset (multiple of 16) of image i's unstuffed stream in `ustream`;
+                             //     streams need as many bytes as their raw scans, rounded up to 16
+    uint8_t* ustream;
+    uint32_t* chunk_drops;   // [n][n_chunks] stuffed zeros per raw chunk
+    uint64_t* chunk_base;    // [n][n_chunks] exclusive scan
+    uint64_t* img_drops;     // [n]
+    uint32_t* sub_end;       // [n][subs] decoder state at the end of each sub-sequence
+    uint32_t* sub_used;      // [n][subs] state the sub-sequence was last decoded from
+    int4* sub_info;          // [n][subs] blocks completed, DC-difference sums of Y, Cb, Cr
+    int4* grp_sum;           // [n][n_groups]
+    int4* grp_base;          // [n][n_groups] exclusive scan
+    uint32_t* changed;       // [4] round flags
+};
+
+// Enqueues the whole decode and, unlike the other launchers, waits on the stream
+// between synchronisation rounds (it has to read back whether a round changed
+// anything).  d_coefs is overwritten completely; errors go to *d_status.
+hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
+                                 const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
+                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status);
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
                          const QuantTables& q, uint8_t* d_rgb);

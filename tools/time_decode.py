@@ -1,0 +1,23 @@
+"""Time the GPU decode (entropy decode + inverse transform) of device-resident files."""
+import importlib, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+sys.path.insert(0, "oracle")
+jea = importlib.import_module("jpeg-encoder_amd")
+import pyoracle as po
+import torch
+
+w, h, q, mode, n = (int(a) for a in sys.argv[1:6])
+ctx = jea.Context(0)
+lum, chrom = jea.binding.quant_tables(q)
+rgb = po.gen_image(w, h, mode, 1234)
+d_rgb = ctx.to_device(np.tile(rgb.reshape(-1), n))
+out, off, size = ctx.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=n * int(jea.binding.max_jpeg_bytes(w, h)) if w * h < 1 << 22 else n * (64 << 20))
+offs = [int(o) for o in off]; sizes = [int(s) for s in size]
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    dec = ctx.decode_batch(out, offs, sizes, w, h, lum, chrom)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f"decode {n} x {w}x{h} q{q} mode{mode}: {1e3*(t1-t0):.3f} ms  {n*w*h/(t1-t0)/1e6:.0f} MPix/s  file {sizes[0]} B")
+want = po.decode(out.cpu().numpy()[offs[0]:offs[0] + sizes[0]].tobytes(), w, h, q)
+print("matches oracle:", np.array_equal(dec.cpu().numpy().reshape(n, h, w, 3)[n - 1], want))
