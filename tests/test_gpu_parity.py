@@ -244,6 +244,62 @@ def test_decode_batch(ctx, po, jea):
         assert np.array_equal(got[i], po.decode(files[i], w, h, quality)), i
 
 
+def test_decode_long_streams_and_uneven_batch(ctx, po, jea):
+    """Streams that span many decoder workgroups, and a batch whose files differ widely in length."""
+    w, h, quality = 520, 333, 100
+    lum, chrom = jea.binding.quant_tables(quality)
+    jpeg = po.encode(po.gen_image(w, h, 1, 5), quality)
+    assert len(jpeg) > 400000
+    assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(jpeg, w, h, quality))
+    w, h, quality, n = 320, 240, 90, 6
+    lum, chrom = jea.binding.quant_tables(quality)
+    files = [po.encode(po.gen_image(w, h, 1 if i in (1, 4) else 0, 40 + i), quality) for i in range(n)]
+    offsets, blob = [], b""
+    for f in files:
+        offsets.append(len(blob))
+        blob += f + b"\xff" * (-len(f) % 16)       # padding that must never be read as stream data
+    got = ctx.decode_batch(ctx.to_device(np.frombuffer(blob, np.uint8)), offsets, [len(f) for f in files], w, h, lum,
+                           chrom).cpu().numpy().reshape(n, h, w, 3)
+    for i in range(n):
+        assert np.array_equal(got[i], po.decode(files[i], w, h, quality)), i
+
+
+def test_decode_damaged_streams_agree_with_oracle(ctx, po, jea):
+    """A damaged scan either fails in both decoders or decodes to the same picture in both
+    (entropy_encoder.cpp:775-777,825-827 and the bounds of :122-144; encoder.cpp:63-65)."""
+    w, h, quality = 72, 56, 75
+    lum, chrom = jea.binding.quant_tables(quality)
+    rng = np.random.RandomState(99)
+    outcomes = {"both fail": 0, "both decode": 0}
+    for mode in (0, 1):
+        jpeg = po.encode(po.gen_image(w, h, mode, 3), quality)
+        variants = []
+        for _ in range(40):
+            bad = bytearray(jpeg)
+            i = rng.randint(607, len(jpeg) - 2)
+            bad[i] ^= 1 << rng.randint(8)
+            variants.append(bytes(bad))
+        for cut in (1, 7, 64, 300):                              # truncated, end marker kept
+            if len(jpeg) - 2 - cut > 607:
+                variants.append(jpeg[: len(jpeg) - 2 - cut] + b"\xff\xd9")
+        variants.append(jpeg[:-2] + bytes(rng.randint(0, 256, 200).astype(np.uint8)) + b"\xff\xd9")   # trailing junk
+        variants.append(jpeg[:607] + bytes(rng.randint(0, 256, 3000).astype(np.uint8)) + b"\xff\xd9")  # all junk
+        for v in variants:
+            try:
+                want = po.decode(v, w, h, quality)
+            except RuntimeError:
+                want = None
+            try:
+                got = ctx.decode_host(v, w, h, lum, chrom)
+            except jea.JeaError:
+                got = None
+            assert (want is None) == (got is None)
+            if want is not None:
+                assert np.array_equal(got, want)
+            outcomes["both fail" if want is None else "both decode"] += 1
+    assert outcomes["both fail"] > 0 and outcomes["both decode"] > 0, outcomes
+
+
 def test_decode_errors(ctx, po, jea):
     """Error surface of encoder.cpp:63-65,140-283 and entropy_encoder.cpp:776."""
     w, h, quality = 32, 32, 75
