@@ -97,26 +97,29 @@ void build_codes(const uint8_t bits[16], const uint8_t* vals, uint32_t* out /* i
     }
 }
 
-void build_decode_table(const uint8_t bits[16], const uint8_t* vals, DecodeTable& t) {
+// Returns false when the codes longer than 9 bits span more 16-bit prefixes than the slow table holds.
+bool build_decode_table(const uint8_t bits[16], const uint8_t* vals, DecodeTable& t) {
     std::memset(&t, 0, sizeof(t));
+    t.first_long = 65536;
     uint32_t code = 0;
     int k = 0;
     for (int l = 1; l <= 16; ++l) {
-        t.maxcode[l] = -1;
-        t.valoff[l] = k - (int)code;
         for (int i = 0; i < bits[l - 1]; ++i, ++k) {
-            t.vals[k] = vals[k];
+            const uint16_t entry = (uint16_t)((l << 8) | vals[k]);
             if (l <= 9) {
                 const uint32_t first = code << (9 - l);
-                for (uint32_t j = 0; j < (1u << (9 - l)); ++j) t.fast[first + j] = (uint16_t)((l << 8) | vals[k]);
+                for (uint32_t j = 0; j < (1u << (9 - l)); ++j) t.fast[first + j] = entry;
+            } else {
+                const uint32_t first = code << (16 - l);
+                if (t.first_long == 65536) t.first_long = first;
+                if (first + (1u << (16 - l)) - t.first_long > (uint32_t)kDecodeSlowEntries) return false;
+                for (uint32_t j = 0; j < (1u << (16 - l)); ++j) t.slow[first + j - t.first_long] = entry;
             }
-            t.maxcode[l] = (int32_t)code;
             ++code;
         }
         code <<= 1;
     }
-    t.maxcode[0] = -1;
-    t.maxcode[17] = -1;
+    return true;
 }
 
 bool valid_dims(uint16_t w, uint16_t h) { return w >= 1 && h >= 1; }
@@ -254,10 +257,11 @@ int jea_create(int device_id, jea_ctx** out_ctx) {
     build_codes(kAcLumBits, kAcLumVals, ht.ac[0], 256);
     build_codes(kAcChrBits, kAcChrVals, ht.ac[1], 256);
     DecodeTables dt;
-    build_decode_table(kDcLumBits, kDcVals, dt.tab[0]);
-    build_decode_table(kAcLumBits, kAcLumVals, dt.tab[1]);
-    build_decode_table(kDcChrBits, kDcVals, dt.tab[2]);
-    build_decode_table(kAcChrBits, kAcChrVals, dt.tab[3]);
+    if (!build_decode_table(kDcLumBits, kDcVals, dt.tab[0]) || !build_decode_table(kAcLumBits, kAcLumVals, dt.tab[1]) ||
+        !build_decode_table(kDcChrBits, kDcVals, dt.tab[2]) || !build_decode_table(kAcChrBits, kAcChrVals, dt.tab[3])) {
+        jea_destroy(ctx);
+        return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: Huffman tables do not fit the decode tables");
+    }
     if ((e = hipMalloc((void**)&ctx->d_huff, sizeof(HuffTables))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->d_decode, sizeof(DecodeTables))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->d_status, 64)) != hipSuccess) return bail("hipMalloc", e);
@@ -705,18 +709,20 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
                               size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs) {
     std::vector<uint64_t> seg(3 * n_images);   // offsets | sizes | unstuffed bases
     uint64_t max_size = 0, ubytes = 0;
+    bool too_short = false;   // reported after the headers have been looked at, as the reference would
     for (size_t i = 0; i < n_images; ++i) {
-        if (h_sizes[i] < skip + 2) return fail(ctx, JEA_ERR_NO_EOI, "Failed to find EOI marker");
+        if (h_sizes[i] < skip) return fail(ctx, JEA_ERR_BAD_HEADER, "Failed to find SOI marker");
+        if (h_sizes[i] < skip + 2) too_short = true;
         seg[i] = h_offsets[i] + skip;
         seg[n_images + i] = h_sizes[i] - skip;
         seg[2 * n_images + i] = ubytes;
         ubytes += (h_sizes[i] - skip + 15) / 16 * 16 + 16;
         if (h_sizes[i] - skip > max_size) max_size = h_sizes[i] - skip;
     }
-    if (mcus * 3 > 0x7fffffffull || max_size * 8 / (32 * kDecodeSubWords) > 0x7fffffffull)
+    if (mcus * 3 > 0x7fffffffull || max_size > (1ull << 34))
         return fail(ctx, JEA_ERR_INVALID_ARG, "decode: image or stream too large");
     const DecodePlan plan = plan_entropy_decode(n_images, max_size, mcus);
-    const size_t subs = (size_t)plan.n_groups * 256;
+    const size_t subs = plan.subs_per_image;
     int rc;
     if ((rc = ensure(ctx, ctx->seg_offsets, 3 * n_images * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ustream, ubytes))) return rc;
@@ -733,6 +739,22 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     JEA_HIP(ctx, hipMemcpy(ctx->seg_offsets.ptr, seg.data(), seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     const uint64_t* d_seg = (const uint64_t*)ctx->seg_offsets.ptr;
+    if (skip == JEA_HEADER_BYTES) {
+        // Header validation on the host, as the reference does before touching scan data (encoder.cpp:48);
+        // one gather and one transfer for the whole batch.
+        if ((rc = ensure(ctx, ctx->small, n_images * JEA_HEADER_BYTES))) return rc;
+        std::vector<uint8_t> hdr(n_images * JEA_HEADER_BYTES);
+        launch_gather_headers(ctx->stream, d_data, d_seg, n_images, JEA_HEADER_BYTES, (uint8_t*)ctx->small.ptr);
+        JEA_HIP(ctx, hipGetLastError());
+        JEA_HIP(ctx, hipMemcpyAsync(hdr.data(), ctx->small.ptr, hdr.size(), hipMemcpyDeviceToHost, ctx->stream));
+        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < n_images; ++i) {
+            const char* msg = nullptr;
+            if (jea_check_header(hdr.data() + i * JEA_HEADER_BYTES, JEA_HEADER_BYTES, nullptr, nullptr, &msg) != JEA_OK)
+                return fail(ctx, JEA_ERR_BAD_HEADER, msg);
+        }
+    }
+    if (too_short) return fail(ctx, JEA_ERR_NO_EOI, "Failed to find EOI marker");
     DecodeScratch sc;
     sc.ubase = d_seg + 2 * n_images;
     sc.ustream = (uint8_t*)ctx->ustream.ptr;
@@ -771,17 +793,8 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
         !valid_dims(width, height) || !tables_ok(lum_q, chr_q))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_decode_batch: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
-    // Header validation on the host, as the reference does before touching scan data (encoder.cpp:48).
-    std::vector<uint8_t> hdr(JEA_HEADER_BYTES);
-    for (size_t i = 0; i < n_images; ++i) {
+    for (size_t i = 0; i < n_images; ++i)
         if (h_sizes[i] < JEA_HEADER_BYTES) return fail(ctx, JEA_ERR_BAD_HEADER, "Failed to find SOI marker");
-        JEA_HIP(ctx, hipMemcpyAsync(hdr.data(), d_jpeg + h_offsets[i], JEA_HEADER_BYTES, hipMemcpyDeviceToHost,
-                                    ctx->stream));
-        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const char* msg = nullptr;
-        if (jea_check_header(hdr.data(), JEA_HEADER_BYTES, nullptr, nullptr, &msg) != JEA_OK)
-            return fail(ctx, JEA_ERR_BAD_HEADER, msg);
-    }
     const size_t mcus = mcus_of(width, height);
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;

@@ -33,6 +33,7 @@
 // entries fill all 63 AC positions loses the final one.
 #include <hip/hip_runtime.h>
 
+#include "huffman_device.h"
 #include "kernels.h"
 #include "../../include/jpegenc_amd.h"
 
@@ -42,11 +43,16 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr uint32_t kChunkBytes = 4096;            // raw bytes per workgroup of the unstuffing passes
-constexpr uint32_t kSubWords = kDecodeSubWords;   // 32-bit words per sub-sequence
-constexpr uint32_t kSubBits = 32 * kSubWords;
-constexpr uint32_t kGroupWords = kThreads * kSubWords;
 constexpr uint32_t kNoState = 0xffffffffu;
-static_assert(kSubBits >= 64, "a symbol (27 bits at most) must fit well inside a sub-sequence");
+// Sub-sequence sizes in 32-bit words (template parameter W below).  Short ones give small streams
+// enough threads to fill the GPU; long ones keep the per-sub-sequence bookkeeping of big streams small.
+// A symbol is at most 27 bits, well inside the smallest size.
+constexpr uint32_t kSubWordsSmall = 2, kSubWordsMedium = 4, kSubWordsLarge = 16;
+// A workgroup owns kOwned consecutive sub-sequences.  In the first round its first kWarm threads
+// decode the last sub-sequences of the previous workgroup once more, only to hand the first owned
+// sub-sequence a start state that has most likely synchronised already.
+constexpr uint32_t kWarm = 16;
+constexpr uint32_t kOwned = kThreads - kWarm;
 
 // state word: bits 0-7 bit offset past the sub-sequence start, 8-9 channel, 16-21 zig-zag progress
 __device__ __forceinline__ uint32_t make_state(uint32_t ovf, uint32_t c, uint32_t z) { return ovf | (c << 8) | (z << 16); }
@@ -171,48 +177,29 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
 // The words of one workgroup's 256 sub-sequences plus one more word, MSB-first
 // values, padded by one word per sub-sequence so that threads reading the same
 // word of their own sub-sequences hit different LDS banks.
+template <uint32_t W>
 struct GroupWords {
-    uint32_t w[(kThreads + 1) * (kSubWords + 1)];
-    __device__ __forceinline__ uint32_t at(uint32_t wi) const { return w[wi + wi / kSubWords]; }
+    uint32_t w[(kThreads + 1) * (W + 1)];
+    __device__ __forceinline__ uint32_t at(uint32_t wi) const { return w[wi + wi / W]; }
 };
 
-__device__ __forceinline__ void stage_group(GroupWords& gw, const uint8_t* __restrict__ stream, uint64_t ulen,
-                                            uint32_t group) {
-    const uint64_t first_word = (uint64_t)group * kGroupWords;
-    for (uint32_t i = threadIdx.x; i < kGroupWords + 1; i += kThreads) {
-        const uint64_t byte = (first_word + i) * 4;
+// first_sub: sub-sequence held by the first slot; negative slots (before the stream) read as zero.
+template <uint32_t W>
+__device__ __forceinline__ void stage_group(GroupWords<W>& gw, const uint8_t* __restrict__ stream, uint64_t ulen,
+                                            int64_t first_sub) {
+    const int64_t first_word = first_sub * (int64_t)W;
+    for (uint32_t i = threadIdx.x; i < kThreads * W + 1; i += kThreads) {
+        const int64_t word = first_word + i;
+        const uint64_t byte = (uint64_t)word * 4;
         uint32_t v = 0;
-        if (byte + 4 <= ulen) {
+        if (word < 0) {
+        } else if (byte + 4 <= ulen) {
             v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(stream + byte));
         } else {
             for (int k = 0; k < 4; ++k)
                 if (byte + k < ulen) v |= (uint32_t)stream[byte + k] << (24 - 8 * k);
         }
-        gw.w[i + i / kSubWords] = v;
-    }
-}
-
-// Canonical decode of the code word at the top of v: 9-bit table, then the
-// max-code-per-length walk (T.81 F.2.2.3), which is what growing a candidate
-// code bit by bit until it equals a code word (entropy_encoder.cpp:767-778,
-// 810-828) amounts to for these prefix codes.  len = 0: no code word matches.
-__device__ __forceinline__ void huff_lookup(const DecodeTable& t, uint32_t v, uint32_t& len, uint32_t& sym) {
-    const uint32_t e = t.fast[v >> 23];
-    if (e) {
-        len = e >> 8;
-        sym = e & 0xffu;
-        return;
-    }
-    const uint32_t p16 = v >> 16;
-    len = 0;
-    sym = 0;
-    for (uint32_t l = 10; l <= 16; ++l) {
-        const int code = (int)(p16 >> (16 - l));
-        if (code <= t.maxcode[l]) {
-            len = l;
-            sym = t.vals[(code + t.valoff[l]) & 255];
-            return;
-        }
+        gw.w[i + i / W] = v;
     }
 }
 
@@ -238,9 +225,10 @@ struct WriteTarget {
 // symbol boundary at or past the end of the sub-sequence.  Malformed symbols do
 // not stop the walk (one bit is skipped), so that a walk from a wrong guess
 // always ends; on the true chain they are reported through WriteTarget::error.
-template <bool kWrite>
-__device__ __forceinline__ uint32_t walk(const GroupWords& gw, const DecodeTables& t, uint32_t sub, uint32_t state,
+template <bool kWrite, uint32_t W>
+__device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTables& t, uint32_t sub, uint32_t state,
                                          Sums& sums, WriteTarget* wt) {
+    constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
     uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
     const uint32_t end = (sub + 1) * kSubBits;
@@ -254,17 +242,22 @@ __device__ __forceinline__ uint32_t walk(const GroupWords& gw, const DecodeTable
             lo = gw.at(wi + 1);
         }
         const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) << (p & 31u) >> 32);
-        uint32_t len, sym;
+        // One path for DC and AC symbols: the threads of a wave are in different
+        // places of their blocks, so separate branches would both run every time.
+        const bool is_dc = z == 0;
+        const uint32_t e = huff_entry(t.tab[(c ? 2u : 0u) + (is_dc ? 0u : 1u)], v >> 16);
+        const uint32_t len = e >> 8, sym = e & 0xffu;
+        const uint32_t ss = is_dc ? sym : (sym & 15u);     // amplitude bits that follow the code word
+        const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
+        if (bad) {
+            if (kWrite) wt->error = true;
+            p += 1;
+            continue;
+        }
+        p += len + ss;
         bool block_done = false;
-        if (z == 0) {
-            huff_lookup(t.tab[c ? 2 : 0], v, len, sym);
-            if (len == 0 || sym > 11) {
-                if (kWrite) wt->error = true;
-                p += 1;
-                continue;
-            }
-            const int diff = sym ? amplitude(v, len, sym) : 0;
-            p += len + sym;
+        if (is_dc) {
+            const int diff = ss ? amplitude(v, len, ss) : 0;
             dc0 += (c == 0) ? diff : 0;
             dc1 += (c == 1) ? diff : 0;
             dc2 += (c == 2) ? diff : 0;
@@ -276,27 +269,15 @@ __device__ __forceinline__ uint32_t walk(const GroupWords& gw, const DecodeTable
             }
             z = 1;
         } else {
-            huff_lookup(t.tab[c ? 3 : 1], v, len, sym);
-            const uint32_t ss = sym & 15u;
-            if (len == 0 || (ss == 0 && sym != 0x00 && sym != 0xF0) || ss > 10) {
-                if (kWrite) wt->error = true;
-                p += 1;
-                continue;
-            }
-            p += len + ss;
-            if (sym == 0x00) {
-                block_done = true;                     // EOB
+            const uint32_t processed = z + (sym >> 4);   // AC positions consumed including this entry
+            if (sym == 0x00 || processed >= 63) {
+                // EOB, or the block is full: then this entry, being the last, is dropped
+                // (entropy_encoder.cpp:129); more than 63 is a stream error for the serial decoder
+                if (kWrite && sym != 0x00 && processed > 63) wt->error = true;
+                block_done = true;
             } else {
-                const uint32_t processed = z + (sym >> 4);   // AC positions consumed including this entry
-                if (processed >= 63) {
-                    // == 63: the block is full and this entry, being the last, is dropped
-                    // (entropy_encoder.cpp:129); > 63 is a stream error for the serial decoder
-                    if (kWrite && processed > 63) wt->error = true;
-                    block_done = true;
-                } else {
-                    if (kWrite && ss) wt->out[(size_t)wt->block * 64 + processed] = (int16_t)amplitude(v, len, ss);
-                    z = processed + 1;
-                }
+                if (kWrite && ss) wt->out[(size_t)wt->block * 64 + processed] = (int16_t)amplitude(v, len, ss);
+                z = processed + 1;
             }
         }
         if (block_done) {
@@ -316,6 +297,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords& gw, const DecodeTable
     return make_state(p >= end ? p - end : 0, c, z);
 }
 
+template <uint32_t W>
 __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __restrict__ ustream,
                                                                const uint64_t* __restrict__ ubase,
                                                                const uint64_t* __restrict__ sizes,
@@ -327,43 +309,59 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                int4* __restrict__ sub_info,
                                                                int4* __restrict__ grp_sum,
                                                                uint32_t* __restrict__ changed) {
-    __shared__ GroupWords gw;
+    constexpr uint32_t kSubBits = 32 * W;
+    __shared__ GroupWords<W> gw;
     __shared__ DecodeTables t;
-    __shared__ uint32_t ends[kThreads + 1];   // ends[i] = state at the start of sub-sequence i
+    __shared__ uint32_t ends[kThreads + 1];   // ends[i] = state at the start of the sub-sequence in slot i
     __shared__ Sums red[4];
 
     const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const uint64_t ulen = sizes[img] - img_drops[img];
     const uint64_t total_bits = 8 * ulen;
-    const size_t sub_index = ((size_t)img * n_groups + group) * kThreads + tid;
-    const uint64_t first_bit = ((uint64_t)group * kThreads + tid) * kSubBits;
-    if ((uint64_t)group * kThreads * kSubBits >= total_bits) {   // nothing of the stream in this group
+    if ((uint64_t)group * kOwned * kSubBits >= total_bits) {   // nothing of the stream in this group
         if (first_round && tid == 0) grp_sum[(size_t)img * n_groups + group] = make_int4(0, 0, 0, 0);
         return;
     }
-    const bool active = first_bit < total_bits;
-
-    for (uint32_t i = tid; i < sizeof(DecodeTables) / 4; i += kThreads)
-        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
-    stage_group(gw, ustream + ubase[img], ulen, group);
+    // slot tid holds sub-sequence first_sub + tid; slots below kWarm belong to the previous group
+    const int64_t first_sub = (int64_t)group * kOwned - kWarm;
+    const int64_t sub = first_sub + tid;
+    const bool owned = tid >= kWarm;
+    const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + (tid - kWarm);   // owned slots only
+    const bool in_stream = sub >= 0 && (uint64_t)sub * kSubBits < total_bits;
+    const bool active = in_stream && (owned || (first_round && group > 0));
 
     uint32_t used = kNoState, my_end = 0;
     Sums sums{0, 0, 0, 0};
     if (!first_round) {
-        my_end = sub_end[sub_index];
-        used = sub_used[sub_index];
-        const int4 s = sub_info[sub_index];
-        sums = Sums{s.x, s.y, s.z, s.w};
-    }
-    ends[tid + 1] = my_end;
-    if (tid == 0) {
-        // the image starts in state 0; a later group starts where the previous one ended, which in
-        // the first round is not known yet and guessed as state 0
+        // The previous round left every group consistent in itself, so only the first owned
+        // sub-sequence can have a new start state: the end state of the group before.
         uint32_t entry = 0;
-        if (group > 0 && !first_round)
-            entry = __atomic_load_n(&sub_end[sub_index - 1], __ATOMIC_RELAXED);
-        ends[0] = entry;
+        bool need = false;
+        if (tid == kWarm) {
+            used = sub_used[sub_index];
+            if (group > 0) entry = __atomic_load_n(&sub_end[sub_index - 1], __ATOMIC_RELAXED);
+            need = active && entry != used;
+        }
+        if (!__syncthreads_or(need ? 1 : 0)) return;
+        if (owned) {
+            my_end = sub_end[sub_index];
+            used = sub_used[sub_index];
+            const int4 s = sub_info[sub_index];
+            sums = Sums{s.x, s.y, s.z, s.w};
+        }
+        if (tid == kWarm) ends[kWarm] = entry;
+        if (owned) ends[tid + 1] = my_end;
+    } else {
+        // Every slot starts from the guess "state 0 at its first bit"; for the first slot of the
+        // image that is the true state.  The warm-up slots of the first group lie before the
+        // stream and stay idle.
+        ends[tid + 1] = 0;
+        if (tid == 0) ends[0] = 0;
     }
+
+    for (uint32_t i = tid; i < sizeof(DecodeTables) / 4; i += kThreads)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
+    stage_group(gw, ustream + ubase[img], ulen, first_sub);
     __syncthreads();
 
     bool dirty = false;
@@ -371,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         const uint32_t start = ends[tid];
         const bool redo = active && start != used;
         if (redo) {
-            my_end = walk<false>(gw, t, tid, start, sums, nullptr);
+            my_end = walk<false, W>(gw, t, tid, start, sums, nullptr);
             used = start;
             dirty = true;
         }
@@ -380,18 +378,19 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         if (!__syncthreads_or(redo ? 1 : 0)) break;
     }
 
+    dirty = dirty && owned;
     const int any_dirty = __syncthreads_or(dirty ? 1 : 0);
     if (dirty) {
         __atomic_store_n(&sub_end[sub_index], my_end, __ATOMIC_RELAXED);
         sub_used[sub_index] = used;
         sub_info[sub_index] = make_int4(sums.nb, sums.dc0, sums.dc1, sums.dc2);
-    } else if (first_round) {   // sub-sequences past the end of the stream
+    } else if (first_round && owned) {   // sub-sequences past the end of the stream
         sub_end[sub_index] = 0;
         sub_used[sub_index] = kNoState;
         sub_info[sub_index] = make_int4(0, 0, 0, 0);
     }
     if (any_dirty || first_round) {
-        Sums v = sums;
+        Sums v = owned ? sums : Sums{0, 0, 0, 0};
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1)
             v = v + Sums{__shfl_xor(v.nb, d), __shfl_xor(v.dc0, d), __shfl_xor(v.dc1, d), __shfl_xor(v.dc2, d)};
@@ -434,6 +433,7 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
     if (threadIdx.x == 0 && (uint32_t)carry_s.nb < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
 }
 
+template <uint32_t W>
 __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* __restrict__ ustream,
                                                                 const uint64_t* __restrict__ ubase,
                                                                 const uint64_t* __restrict__ sizes,
@@ -445,26 +445,28 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const int4* __restrict__ grp_base,
                                                                 int16_t* __restrict__ coefs,
                                                                 int32_t* __restrict__ status) {
-    __shared__ GroupWords gw;
+    constexpr uint32_t kSubBits = 32 * W;
+    __shared__ GroupWords<W> gw;
     __shared__ DecodeTables t;
     __shared__ Sums lds4[4];
 
     const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const uint64_t ulen = sizes[img] - img_drops[img];
     const uint64_t total_bits = 8 * ulen;
-    if ((uint64_t)group * kThreads * kSubBits >= total_bits) return;
+    if ((uint64_t)group * kOwned * kSubBits >= total_bits) return;
     const int4 gb = grp_base[(size_t)img * n_groups + group];
     if ((uint32_t)gb.x >= total_blocks) return;   // the picture is complete before this group
-    const size_t sub_index = ((size_t)img * n_groups + group) * kThreads + tid;
-    const uint64_t first_bit = ((uint64_t)group * kThreads + tid) * kSubBits;
-    const bool active = first_bit < total_bits;
+    // slot tid holds the group's tid-th sub-sequence; the last kWarm threads have none
+    const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + tid;
+    const uint64_t first_bit = ((uint64_t)group * kOwned + tid) * kSubBits;
+    const bool active = tid < kOwned && first_bit < total_bits;
 
     for (uint32_t i = tid; i < sizeof(DecodeTables) / 4; i += kThreads)
         reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
     const uint8_t* stream = ustream + ubase[img];
-    stage_group(gw, stream, ulen, group);
+    stage_group(gw, stream, ulen, (int64_t)group * kOwned);
 
-    const int4 si = sub_info[sub_index];
+    const int4 si = tid < kOwned ? sub_info[sub_index] : make_int4(0, 0, 0, 0);
     Sums total;
     const Sums before = block_exclusive_scan(Sums{si.x, si.y, si.z, si.w}, lds4, total);   // also orders the staging
     WriteTarget wt;
@@ -480,14 +482,14 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     if (!active || wt.block >= total_blocks) return;
 
     Sums sums;
-    (void)walk<true>(gw, t, tid, sub_used[sub_index], sums, &wt);
+    (void)walk<true, W>(gw, t, tid, sub_used[sub_index], sums, &wt);
     if (wt.error) {
         // a malformed symbol outranks a missing end marker, as in the serial order of checks
         const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
         if (old == JEA_ERR_NO_EOI) atomicCAS(status, JEA_ERR_NO_EOI, JEA_ERR_BAD_STREAM);
     }
     if (wt.finished) {
-        const uint64_t end_bit = (uint64_t)group * kThreads * kSubBits + wt.final_bit;
+        const uint64_t end_bit = (uint64_t)group * kOwned * kSubBits + wt.final_bit;
         if (end_bit > total_bits) {   // bits past the end of the file were consumed
             const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
             if (old == JEA_ERR_NO_EOI) atomicCAS(status, JEA_ERR_NO_EOI, JEA_ERR_BAD_STREAM);
@@ -532,23 +534,78 @@ __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t* __res
 
 }  // namespace
 
+namespace {
+__global__ void gather_headers_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ scan_offsets,
+                                      uint32_t header_bytes, uint8_t* __restrict__ out) {
+    const uint8_t* src = data + scan_offsets[blockIdx.x] - header_bytes;
+    for (uint32_t i = threadIdx.x; i < header_bytes; i += blockDim.x) out[(size_t)blockIdx.x * header_bytes + i] = src[i];
+}
+}  // namespace
+
+void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
+                           uint32_t header_bytes, uint8_t* d_out) {
+    gather_headers_kernel<<<(unsigned)n_images, 256, 0, s>>>(d_data, d_scan_offsets, header_bytes, d_out);
+}
+
 DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image) {
     DecodePlan p;
     p.n_images = (uint32_t)n_images;
     p.n_chunks = (uint32_t)((max_scan_bytes + kChunkBytes - 1) / kChunkBytes);
-    const uint64_t subs = ((uint64_t)max_scan_bytes * 8 + kSubBits - 1) / kSubBits;
-    p.n_groups = (uint32_t)((subs + kThreads - 1) / kThreads);
     if (p.n_chunks == 0) p.n_chunks = 1;
-    if (p.n_groups == 0) p.n_groups = 1;
+    // the longest sub-sequences that still give the GPU a few workgroups per compute unit
+    const uint32_t sizes[3] = {kSubWordsLarge, kSubWordsMedium, kSubWordsSmall};
+    for (uint32_t w : sizes) {
+        const uint64_t subs = ((uint64_t)max_scan_bytes * 8 + 32 * w - 1) / (32 * w);
+        p.sub_words = w;
+        p.n_groups = (uint32_t)((subs + kOwned - 1) / kOwned);
+        if (p.n_groups == 0) p.n_groups = 1;
+        if ((uint64_t)p.n_groups * n_images >= 512) break;
+    }
+    p.subs_per_image = (size_t)p.n_groups * kOwned;
     p.total_blocks = (uint32_t)(mcus_per_image * 3);
     return p;
 }
+
+namespace {
+template <uint32_t W>
+hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
+                      const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status) {
+    hipError_t e;
+    const dim3 ggrid(p.n_groups, p.n_images);
+    // Three rounds up front: the first decodes everything, the second repairs the starts of the
+    // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.
+    for (int r = 0; r < 3; ++r)
+        decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                         r == 0 ? 1 : 0, d_tables, sc.sub_end, sc.sub_used,
+                                                         sc.sub_info, sc.grp_sum, sc.changed + r);
+    uint32_t changed = 0;
+    if ((e = hipMemcpyAsync(&changed, sc.changed + 2, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    // Streams that do not re-synchronise within a workgroup's sub-sequences need one more round
+    // per workgroup the error travels through; n_groups rounds always suffice.
+    for (uint32_t extra = 0; changed != 0; ++extra) {
+        if (extra > p.n_groups + 1) return hipErrorUnknown;
+        if ((e = hipMemsetAsync(sc.changed + 3, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
+        decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, 0,
+                                                         d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
+                                                         sc.changed + 3);
+        if ((e = hipMemcpyAsync(&changed, sc.changed + 3, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess)
+            return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    }
+    scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base, d_status);
+    decode_write_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                      p.total_blocks, d_tables, sc.sub_used, sc.sub_info, sc.grp_base,
+                                                      d_coefs, d_status);
+    return hipGetLastError();
+}
+}  // namespace
 
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
                                  const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status) {
     hipError_t e;
-    const dim3 cgrid(p.n_chunks, p.n_images), ggrid(p.n_groups, p.n_images);
+    const dim3 cgrid(p.n_chunks, p.n_images);
     unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops);
     scan_chunks_kernel<<<p.n_images, 1024, 0, s>>>(sc.chunk_drops, p.n_chunks, sc.chunk_base, sc.img_drops);
     unstuff_compact_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_base, sc.ubase,
@@ -556,32 +613,11 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
     if ((e = hipMemsetAsync(sc.changed, 0, 4 * sizeof(uint32_t), s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(d_coefs, 0, (size_t)p.n_images * p.total_blocks * 64 * sizeof(int16_t), s)) != hipSuccess)
         return e;
-    // Three rounds up front: the first decodes everything, the second repairs the starts of the
-    // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.
-    for (int r = 0; r < 3; ++r)
-        decode_sync_kernel<<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
-                                                      r == 0 ? 1 : 0, d_tables, sc.sub_end, sc.sub_used, sc.sub_info,
-                                                      sc.grp_sum, sc.changed + r);
-    uint32_t changed = 0;
-    if ((e = hipMemcpyAsync(&changed, sc.changed + 2, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    // Streams that do not re-synchronise within a workgroup's 256 sub-sequences need one more
-    // round per workgroup the error travels through; n_groups rounds always suffice.
-    for (uint32_t extra = 0; changed != 0; ++extra) {
-        if (extra > p.n_groups + 1) return hipErrorUnknown;
-        if ((e = hipMemsetAsync(sc.changed + 3, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
-        decode_sync_kernel<<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, 0,
-                                                      d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
-                                                      sc.changed + 3);
-        if ((e = hipMemcpyAsync(&changed, sc.changed + 3, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess)
-            return e;
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    switch (p.sub_words) {
+        case kSubWordsSmall: return run_decode<kSubWordsSmall>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);
+        case kSubWordsMedium: return run_decode<kSubWordsMedium>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);
+        default: return run_decode<kSubWordsLarge>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);
     }
-    scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base, d_status);
-    decode_write_kernel<<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
-                                                   p.total_blocks, d_tables, sc.sub_used, sc.sub_info, sc.grp_base,
-                                                   d_coefs, d_status);
-    return hipGetLastError();
 }
 
 }  // namespace jea

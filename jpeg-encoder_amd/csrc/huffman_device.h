@@ -173,23 +173,23 @@ __device__ __forceinline__ int read_amplitude(SerialReader& r, int ssss) {
 
 // The reference grows a candidate code bit by bit from two bits until it equals
 // a code word of that length (entropy_encoder.cpp:767-778, :810-828); for these
-// prefix codes that is the canonical decode: 9-bit table first, then the
-// max-code-per-length walk of T.81 Annex F.2.2.3.  Returns -1 on an invalid code.
+// prefix codes that is the canonical decode, done here with two table reads.
+// Returns (length << 8) | symbol of the code word at the top of the 16 bits, 0 when none matches.
+__device__ __forceinline__ uint32_t huff_entry(const DecodeTable& t, uint32_t p16) {
+    uint32_t e = t.fast[p16 >> 7];
+    if (e == 0) {
+        const uint32_t idx = p16 - t.first_long;   // wraps to a huge value below first_long
+        e = idx < (uint32_t)kDecodeSlowEntries ? t.slow[idx] : 0u;
+    }
+    return e;
+}
+
+// Returns the symbol, -1 on an invalid code.
 __device__ __forceinline__ int decode_symbol(SerialReader& r, const DecodeTable& t) {
-    const uint32_t e = t.fast[r.peek(9)];
-    if (e) {
-        r.skip((int)(e >> 8));
-        return (int)(e & 0xffu);
-    }
-    const uint32_t p16 = r.peek(16);
-    for (int l = 10; l <= 16; ++l) {
-        const int code = (int)(p16 >> (16 - l));
-        if (code <= t.maxcode[l]) {
-            r.skip(l);
-            return t.vals[code + t.valoff[l]];
-        }
-    }
-    return -1;
+    const uint32_t e = huff_entry(t, r.peek(16));
+    if (e == 0) return -1;
+    r.skip((int)(e >> 8));
+    return (int)(e & 0xffu);
 }
 
 // One block-channel from the serial reader into zz[64] (zig-zag order; the caller

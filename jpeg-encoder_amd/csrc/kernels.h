@@ -28,14 +28,16 @@ struct HuffTables {
 };
 
 // Huffman decode tables, one per (class, DC/AC): index 0 lum-DC, 1 lum-AC,
-// 2 chr-DC, 3 chr-AC.  fast[] resolves codes of up to 9 bits from a 9-bit prefix
-// ((length << 8) | symbol, 0 = longer); longer codes use the per-length
-// max-code walk: symbol = vals[code + valoff[length]] when code <= maxcode[length].
+// 2 chr-DC, 3 chr-AC.  Entries are (length << 8) | symbol, 0 = no code word.
+// fast[] resolves codes of up to 9 bits from the next 9 stream bits.  Canonical
+// codes grow numerically with their length, so all longer codes sit at the top
+// of the 16-bit prefix space: slow[] is indexed by (next 16 bits) - first_long
+// and covers that whole range (640 prefixes for the Annex K AC tables).
+constexpr int kDecodeSlowEntries = 1024;
 struct DecodeTable {
     uint16_t fast[512];
-    int32_t maxcode[18];  // -1 when no code has that length
-    int32_t valoff[18];
-    uint8_t vals[256];
+    uint16_t slow[kDecodeSlowEntries];
+    uint32_t first_long;  // smallest 16-bit prefix that starts a code longer than 9 bits; 65536 when none
 };
 struct DecodeTables {
     DecodeTable tab[4];
@@ -117,17 +119,17 @@ void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, 
 
 // Parallel Huffman decode (decode.hip).  The scan of image i is the byte range
 // [d_offsets[i], d_offsets[i] + d_sizes[i]) of d_scan and ends with the EOI marker.
-constexpr uint32_t kDecodeSubWords = 16;  // 32-bit words of unstuffed stream decoded by one thread
-
 struct DecodePlan {
     uint32_t n_images = 0;
     uint32_t n_chunks = 0;      // 4096-byte pieces of the longest raw scan
-    uint32_t n_groups = 0;      // workgroups (256 sub-sequences each) covering the longest scan
+    uint32_t sub_words = 0;     // 32-bit words of unstuffed stream per sub-sequence (one thread's share)
+    uint32_t n_groups = 0;      // workgroups covering the longest scan
+    size_t subs_per_image = 0;  // sub-sequence records per image
     uint32_t total_blocks = 0;  // block-channels per image
 };
 DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image);
 
-// Caller-provided scratch; n = images, subs = n_groups * 256.
+// Caller-provided scratch; n = images, subs = DecodePlan::subs_per_image.
 struct DecodeScratch {
     const uint64_t* ubase;   // [n] byte offset (multiple of 16) of image i's unstuffed stream in `ustream`;
                              //     streams need as many bytes as their raw scans, rounded up to 16
@@ -149,6 +151,11 @@ struct DecodeScratch {
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
                                  const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status);
+
+// Copies the header_bytes bytes in front of each scan (d_scan_offsets[i] is the scan's offset in
+// d_data) to d_out back to back, so that the host can validate all headers with one transfer.
+void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
+                           uint32_t header_bytes, uint8_t* d_out);
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
                          const QuantTables& q, uint8_t* d_rgb);
