@@ -319,8 +319,44 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     }
     __syncthreads();
 
-    // colour conversion and cropped store: work item = (row r, mcu m, pixel p),
-    // ordered so that consecutive threads write consecutive pixels of a row strip
+    // Colour conversion and cropped store.  Fast path (width a multiple of 8, so every block row
+    // segment is whole and 8-byte aligned): work item = (row r, mcu mm) = 8 pixels = 24 contiguous
+    // bytes; consecutive threads take consecutive MCUs, i.e. consecutive 24-byte pieces of an image row.
+    if ((width & 7) == 0) {
+        for (uint32_t i = tid; i < 8u * mcus_here; i += kFdctThreads) {
+            const uint32_t r = i / mcus_here, mm = i - r * mcus_here;
+            const uint32_t mcu = g0 + mm;
+            const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+            const int y = (int)by * 8 + (int)r;
+            if (y >= height) continue;
+            const uint2 y8 = *reinterpret_cast<const uint2*>(lds_px + (0 * kMcusPerGroup + mm) * 64 + r * 8);
+            const uint2 b8 = *reinterpret_cast<const uint2*>(lds_px + (1 * kMcusPerGroup + mm) * 64 + r * 8);
+            const uint2 r8 = *reinterpret_cast<const uint2*>(lds_px + (2 * kMcusPerGroup + mm) * 64 + r * 8);
+            const uint32_t yy[2] = {y8.x, y8.y}, cbb[2] = {b8.x, b8.y}, crr[2] = {r8.x, r8.y};
+            uint32_t out[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int sh = 8 * (p & 3);
+                uint8_t rr, gg, bb;
+                colour_inverse((int)((yy[p >> 2] >> sh) & 0xffu), (int)((cbb[p >> 2] >> sh) & 0xffu),
+                               (int)((crr[p >> 2] >> sh) & 0xffu), rr, gg, bb);
+                const uint8_t px3[3] = {rr, gg, bb};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int byte = 3 * p + c;
+                    out[byte >> 2] |= (uint32_t)px3[c] << (8 * (byte & 3));
+                }
+            }
+            uint2* dst = reinterpret_cast<uint2*>(img + ((size_t)y * width + (size_t)bx * 8) * 3);
+            dst[0] = make_uint2(out[0], out[1]);
+            dst[1] = make_uint2(out[2], out[3]);
+            dst[2] = make_uint2(out[4], out[5]);
+        }
+        return;
+    }
+    // General path: work item = (row r, mcu m, pixel p), ordered so that consecutive threads
+    // write consecutive pixels of a row strip; pixels outside the picture are dropped
+    // (block_grid.cpp:87-99).
     for (uint32_t i = tid; i < 8u * mcus_here * 8u; i += kFdctThreads) {
         const uint32_t r = i / (mcus_here * 8u), rem = i - r * (mcus_here * 8u);
         const uint32_t mm = rem >> 3, p = rem & 7u;
