@@ -243,18 +243,83 @@ __global__ __launch_bounds__(64) void fdct_quant_wave_kernel(const uint8_t* __re
     if (chunk_masks != nullptr) chunk_masks[((size_t)blockIdx.z * n_mcu + mcu) * 3 + channel] = (uint8_t)mask;
 }
 
+// zig-zag position of natural index n
+constexpr int zigzag_position(int n) {
+    for (int i = 0; i < 64; ++i)
+        if (kZigzag[i] == n) return i;
+    return 0;
+}
+
+// Inverse transform of one block in two steps around a workgroup barrier, so that the sample
+// buffer may reuse the LDS space of the coefficients.  Coefficients outside the triangle
+// u + v <= D are known to be zero (D = 7: no such knowledge).  The sums keep the reference's order
+// and simply stop where only zero terms would follow: adding c * 0 can change nothing but the
+// sign of a zero, which the final truncation to an integer does not see.
+//
+// Row step: de-zigzag (entropy_encoder.cpp:79-92), dequantise (quantiser.cpp:72-85) and row pass
+// (discrete_cosine_transform.cpp:126-135): tmp[x][v] = sum_u (s(u)C[u][x]) * src[u + 8v].
+// `chunk[c]` is the LDS address of the block's 16-byte chunk c (zig-zag positions 8c..8c+7).
+template <int D>
+__device__ __forceinline__ void idct_rows(const uint8_t* const (&chunk)[8], const float* __restrict__ qt,
+                                          float (&tmp)[8][8]) {
+    constexpr int kRows = D < 7 ? D + 1 : 8;
+#pragma unroll
+    for (int v = 0; v < kRows; ++v) {
+        const int terms = (D < 7) ? (D - v + 1) : 8;
+        float deq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < terms) {
+                const int k = zigzag_position(8 * v + u);
+                const int c = (int)*reinterpret_cast<const int16_t*>(chunk[k >> 3] + 2 * (k & 7));
+                deq[u] = (float)c * qt[8 * v + u];
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            float acc = inv_c(0, x) * deq[0];
+#pragma unroll
+            for (int u = 1; u < terms; ++u) acc += inv_c(u, x) * deq[u];
+            tmp[x][v] = acc;
+        }
+    }
+}
+
+// Column step :136-156: out[8y+x] = clamp/truncate(sum_v (s(v)C[v][y]) * tmp[x][v]); +128 (:21-27).
+template <int D>
+__device__ __forceinline__ void idct_cols(const float (&tmp)[8][8], uint8_t* __restrict__ px) {
+    constexpr int kRows = D < 7 ? D + 1 : 8;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        uint32_t packed[2] = {0, 0};
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            float acc = inv_c(0, y) * tmp[x][0];
+#pragma unroll
+            for (int v = 1; v < kRows; ++v) acc += inv_c(v, y) * tmp[x][v];
+            // :144-154: below -128 -> -128, above 127 -> 127, else truncation toward zero; clamping first
+            // gives the same integer without branches
+            const int o = (int)__builtin_amdgcn_fmed3f(acc, -128.0f, 127.0f);
+            packed[x >> 2] |= (uint32_t)(o + 128) << (8 * (x & 3));
+        }
+        *reinterpret_cast<uint2*>(px + y * 8) = make_uint2(packed[0], packed[1]);
+    }
+}
+
 // ---------------------------------------------------------------------------
-// Inverse: de-zigzag + dequantise + IDCT + level unshift + YCbCr->RGB + crop.
-// Same thread mapping as the forward kernel; the three channel planes of the 64
-// MCUs meet in LDS, then each thread colour-converts whole pixels.
+// Decode side: de-zigzag + dequantise + IDCT + level unshift + YCbCr -> RGB.
+// Same work split as the forward kernel (wave = channel, lane = MCU); the three
+// channels of the MCUs meet in LDS, then each thread colour-converts whole pixels.
 // ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_t* __restrict__ coefs, int width,
                                                                     int height, int blocks_w, uint32_t n_mcu,
                                                                     size_t image_bytes, QuantTables q,
                                                                     uint8_t* __restrict__ rgb) {
-    __shared__ __align__(16) uint8_t lds_coef[kFdctThreads * 128];  // rotated chunks, as in the forward kernel
-    __shared__ __align__(16) uint8_t lds_px[3 * kMcusPerGroup * 64 + 16];  // [channel][mcu][64] u8
+    // coefficients as rotated 16-byte chunks (as in the forward kernel); after the row step the
+    // first half is reused for the samples, [channel][mcu][64] u8
+    __shared__ __align__(16) uint8_t lds_coef[kFdctThreads * 128];
+    uint8_t* const lds_px = lds_coef;
 
     const int tid = threadIdx.x;
     const uint32_t g0 = blockIdx.x * kMcusPerGroup;
@@ -272,49 +337,43 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     const int channel = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = tid & 63;
     const uint32_t j = (uint32_t)m * 3 + (uint32_t)channel;
-    if ((uint32_t)m < mcus_here) {
-        const float* qt = channel == 0 ? q.lum : q.chr;
-        // de-zigzag (entropy_encoder.cpp:79-92) and dequantise (quantiser.cpp:72-85)
-        float deq[64];
+    const bool valid = (uint32_t)m < mcus_here;
+    const float* qt = channel == 0 ? q.lum : q.chr;
+    float tmp[8][8];
+    int diag = 7;
+    if (valid) {
+        const uint8_t* chunk[8];
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const uint4 c4 = *reinterpret_cast<const uint4*>(lds_coef + j * 128 + ((((uint32_t)k8 + j) & 7u) << 4));
-            const uint32_t w[4] = {c4.x, c4.y, c4.z, c4.w};
+        for (int c = 0; c < 8; ++c) chunk[c] = lds_coef + j * 128 + ((((uint32_t)c + j) & 7u) << 4);
+        // How far do the non-zero coefficients of this wave's 64 blocks reach along the zig-zag?
+        // The transform is then run on the smallest triangle u + v <= D that holds them all.
+        uint32_t rest = 0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 8 * k8 + e;
-                const int v = (int)(int16_t)(w[e >> 1] >> (16 * (e & 1)));
-                deq[kZigzag[k]] = (float)v * qt[kZigzag[k]];
-            }
+        for (int c = 1; c < 8; ++c) {
+            const uint4 c4 = *reinterpret_cast<const uint4*>(chunk[c]);
+            rest |= c4.x | c4.y | c4.z | c4.w;
         }
-        // Row pass :126-135: tmp[x][v] = sum_u (s(u)C[u][x]) * src[u + 8v]
-        float tmp[8][8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) {
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                float acc = inv_c(0, x) * deq[8 * v];
-#pragma unroll
-                for (int u = 1; u < 8; ++u) acc += inv_c(u, x) * deq[u + 8 * v];
-                tmp[x][v] = acc;
-            }
+        if (__ballot(rest != 0) == 0) {
+            // words of the first chunk: zig-zag positions 0-1 | 2-3 | 4-5 | 6-7, which lie on the
+            // diagonals u + v = 0,1 | 1,2 | 2,2 | 3,3
+            const uint4 c0 = *reinterpret_cast<const uint4*>(chunk[0]);
+            diag = __ballot(c0.w != 0) != 0 ? 3 : ((__ballot((c0.y | c0.z) != 0) != 0) ? 2 : 1);
         }
-        // Column pass :136-156: out[8y+x] = clamp/truncate(sum_v (s(v)C[v][y]) * tmp[x][v]); +128 (:21-27)
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-            uint32_t packed[2] = {0, 0};
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                float acc = inv_c(0, y) * tmp[x][0];
-#pragma unroll
-                for (int v = 1; v < 8; ++v) acc += inv_c(v, y) * tmp[x][v];
-                int o;
-                if (acc < -128.0f) o = -128;
-                else if (acc > 127.0f) o = 127;
-                else o = (int)acc;
-                packed[x >> 2] |= (uint32_t)(o + 128) << (8 * (x & 3));
-            }
-            *reinterpret_cast<uint2*>(lds_px + (channel * kMcusPerGroup + m) * 64 + y * 8) = make_uint2(packed[0], packed[1]);
+        switch (diag) {
+            case 1: idct_rows<1>(chunk, qt, tmp); break;
+            case 2: idct_rows<2>(chunk, qt, tmp); break;
+            case 3: idct_rows<3>(chunk, qt, tmp); break;
+            default: idct_rows<7>(chunk, qt, tmp); break;
+        }
+    }
+    __syncthreads();   // every coefficient has been read: the samples may overwrite them
+    if (valid) {
+        uint8_t* dst = lds_px + (channel * kMcusPerGroup + m) * 64;
+        switch (diag) {
+            case 1: idct_cols<1>(tmp, dst); break;
+            case 2: idct_cols<2>(tmp, dst); break;
+            case 3: idct_cols<3>(tmp, dst); break;
+            default: idct_cols<7>(tmp, dst); break;
         }
     }
     __syncthreads();
