@@ -35,6 +35,38 @@ __device__ __forceinline__ void colour_constants(int channel, double& k, double&
     c = channel == 0 ? 0.114 : (channel == 1 ? 0.5 : -0.081312);
 }
 
+// The same formulas in exact integer arithmetic.  All constants are multiples of 1/M with
+// M = 1000 for Y and M = 31250 for Cb, Cr (0.168736 = 5273/31250, 0.331264 = 10352/31250,
+// 0.5 = 15625/31250, 0.418688 = 13084/31250, 0.081312 = 2541/31250), so that
+//   value = t / M,   t = k + a r + b g + c b   an integer below 2^24 in magnitude,
+// and floor(value + 0.5) - 128 = floor((t + M/2 - 128 M) / M).  The numerator is formed with
+// three FMAs that are exact (every intermediate is an integer below 2^24), the division is a
+// multiply by RN(1/M): q is within 128 * 2^-23 < 3.1e-5 of the true quotient, whose distance to
+// the next integer is either 0 (value + 0.5 is an integer: a rounding tie, where the reference's
+// double arithmetic decides and only the literal double formula can tell which way) or at least
+// 1/M = 3.2e-5.  Quotients closer than 1e-4 to an integer are therefore flagged and redone with
+// colour_forward; for all others floor(q) is the reference's result, and it needs no clamp
+// because an unflagged value + 0.5 lies strictly inside (0, 256).
+struct ColourInt {
+    float k, a, b, c, rcp_m;
+};
+__device__ __forceinline__ ColourInt colour_int_constants(int channel) {
+    ColourInt ci;
+    // k = (constant term) * M + M/2 - 128 M; for the chroma channels 128 M - 128 M cancels
+    if (channel == 0) ci = ColourInt{500.0f - 128000.0f, 299.0f, 587.0f, 114.0f, 1.0f / 1000.0f};
+    else if (channel == 1) ci = ColourInt{15625.0f, -5273.0f, -10352.0f, 15625.0f, 1.0f / 31250.0f};
+    else ci = ColourInt{15625.0f, 15625.0f, -13084.0f, -2541.0f, 1.0f / 31250.0f};
+    return ci;
+}
+// Level-shifted sample (value rounded, minus 128) as a float; `tie` is set when it must be redone.
+__device__ __forceinline__ float colour_forward_shifted_fast(const ColourInt& ci, float r, float g, float b, bool& tie) {
+    const float t = __builtin_fmaf(ci.c, b, __builtin_fmaf(ci.b, g, __builtin_fmaf(ci.a, r, ci.k)));
+    const float q = t * ci.rcp_m;
+    const float fr = __builtin_amdgcn_fractf(q);      // q - floor(q), exact
+    tie = __builtin_fabsf(fr - 0.5f) > 0.4999f;
+    return q - fr;
+}
+
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) {
     return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
 }

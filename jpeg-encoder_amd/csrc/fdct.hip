@@ -101,6 +101,7 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
     if (active) {
         double ck, ca, cb, cc;
         colour_constants(channel, ck, ca, cb, cc);
+        const ColourInt ci = colour_int_constants(channel);
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
             const uint2* src = reinterpret_cast<const uint2*>(lds_in + y * 1536 + m * 24);
@@ -110,13 +111,18 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
-                const double r = (double)((d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu);
-                const double g = (double)((d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu);
-                const double b = (double)((d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu);
-                // floor(v + 0.5) is an integer in [-1, 256]: exact as a float, so the clamp
-                // to [0, 255] (:49-51) can be done there; then "- 128" into int8 (:13-19)
-                const float rounded = (float)floor((((ck + ca * r) + cb * g) + cc * b) + 0.5);
-                f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
+                const uint32_t ri = (d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu;
+                const uint32_t gi = (d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu;
+                const uint32_t bi = (d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu;
+                bool tie;
+                f[p] = colour_forward_shifted_fast(ci, (float)ri, (float)gi, (float)bi, tie);
+                if (__builtin_expect(__any(tie), 0)) {
+                    // the literal formula; floor(v + 0.5) is an integer in [-1, 256]: exact as a float, so
+                    // the clamp to [0, 255] (:49-51) can be done there; then "- 128" into int8 (:13-19)
+                    const float rounded =
+                        (float)floor((((ck + ca * (double)ri) + cb * (double)gi) + cc * (double)bi) + 0.5);
+                    f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
+                }
             }
             fdct_row(f, y, row);
         }
@@ -436,12 +442,18 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
 
 __global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, size_t n, uint8_t* __restrict__ ycc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        const uint32_t ri = rgb[3 * i], gi = rgb[3 * i + 1], bi = rgb[3 * i + 2];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            double ck, ca, cb, cc;
-            colour_constants(ch, ck, ca, cb, cc);
-            ycc[3 * i + ch] = (uint8_t)colour_forward(ck, ca, cb, cc, r, g, b);
+            // the fused kernel's two paths: exact integer arithmetic, literal double formula on rounding ties
+            bool tie;
+            float v = colour_forward_shifted_fast(colour_int_constants(ch), (float)ri, (float)gi, (float)bi, tie) + 128.0f;
+            if (tie) {
+                double ck, ca, cb, cc;
+                colour_constants(ch, ck, ca, cb, cc);
+                v = (float)colour_forward(ck, ca, cb, cc, (double)ri, (double)gi, (double)bi);
+            }
+            ycc[3 * i + ch] = (uint8_t)v;
         }
     }
 }
