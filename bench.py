@@ -147,6 +147,25 @@ def main():
     k1_ms = e0.elapsed_time(e1) / reps
     k1_bytes = K1_BYTES_PER_PIXEL * pixels_per_step
     achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+    # The same kernel with four times the work per launch: the difference is the cost of one more
+    # step's worth of work once the launch's fixed latency (first and last workgroups running on a
+    # half-empty GPU) is paid -- what a stream of back-to-back images sees.
+    steady = None
+    if args.batch * W * H <= 64 << 20:
+        d_rgb4 = d_rgb.repeat(4)
+        d_coefs4 = torch.empty(4 * d_coefs.numel(), dtype=torch.int16, device=dev)
+        with torch.cuda.stream(ext):
+            for _ in range(3):
+                ctx.fdct_quant_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4)
+            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e2.record()
+            for _ in range(20):
+                ctx.fdct_quant_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4)
+            e3.record()
+        ctx.synchronize()
+        k4_ms = e2.elapsed_time(e3) / 20
+        steady = max((k4_ms - k1_ms) / 3, 1e-6)
+        del d_rgb4, d_coefs4
     # HBM bytes per launch from the PMC counters, collected in separate rocprofv3 passes on this same command
     # and corrected for gfx950 as profiles/r01_pmc_traffic.json describes; only valid for the workload it was taken on
     traffic = None
@@ -156,6 +175,9 @@ def main():
     roofline = {"kernel": "fdct_quant_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_us": round(k1_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(k1_bytes)}
+    if steady is not None:
+        roofline["marginal_us_per_step_of_work"] = round(steady * 1e3, 2)
+        roofline["marginal_frac"] = round(k1_bytes / (steady * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
