@@ -122,7 +122,8 @@ def main():
         step()
     sync_all()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0   # this rank's time; the job's is the maximum over ranks (below)
+    barrier()
     assert all(int(o["status"][0].item()) == 0 for o in outs)
 
     # whole-job throughput: all ranks' pixels over the slowest rank's time
