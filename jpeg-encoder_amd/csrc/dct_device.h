@@ -67,8 +67,9 @@ __device__ __forceinline__ float colour_forward_shifted_fast(const ColourInt& ci
     return q - fr;
 }
 
+// low halves of two ints side by side: one byte-permute instruction
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) {
-    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
 }
 
 // Forward-transform constants with the scale folded in where that is exact:

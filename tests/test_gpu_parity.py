@@ -264,6 +264,25 @@ def test_decode_long_streams_and_uneven_batch(ctx, po, jea):
         assert np.array_equal(got[i], po.decode(files[i], w, h, quality)), i
 
 
+@pytest.mark.parametrize("copies", [6, 20])
+def test_decode_batches_that_select_longer_subsequences(ctx, po, jea, copies):
+    """The decoder cuts streams into sub-sequences of 2, 4 or 16 words depending on how much stream the
+    job holds; 6 and 20 long noise streams select the 4- and 16-word variants."""
+    w, h, quality = 520, 333, 100
+    lum, chrom = jea.binding.quant_tables(quality)
+    files = [po.encode(po.gen_image(w, h, 1, 70 + i), quality) for i in range(2)]
+    want = [po.decode(f, w, h, quality) for f in files]
+    offsets, sizes, blob = [], [], b""
+    for i in range(copies):
+        f = files[i % 2]
+        offsets.append(len(blob)); sizes.append(len(f))
+        blob += f + b"\0" * (-len(f) % 64)
+    got = ctx.decode_batch(ctx.to_device(np.frombuffer(blob, np.uint8)), offsets, sizes, w, h, lum,
+                           chrom).cpu().numpy().reshape(copies, h, w, 3)
+    for i in range(copies):
+        assert np.array_equal(got[i], want[i % 2]), i
+
+
 def test_decode_damaged_streams_agree_with_oracle(ctx, po, jea):
     """A damaged scan either fails in both decoders or decodes to the same picture in both
     (entropy_encoder.cpp:775-777,825-827 and the bounds of :122-144; encoder.cpp:63-65)."""
