@@ -165,6 +165,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     if ((rc = ensure(ctx, ctx->unstuffed, ucap))) return rc;
     sc.len16 = (uint16_t*)ctx->len16.ptr;
     sc.chunk_masks = nullptr;  // set by callers whose coefficients come with masks from the forward kernel
+    sc.planar = false;
     sc.slots = (uint32_t*)ctx->slots.ptr;
     sc.tile_bits = (uint32_t*)ctx->tile_bits.ptr;
     sc.tile_base = (uint64_t*)ctx->tile_base.ptr;
@@ -500,11 +501,12 @@ int jea_block_bit_lengths(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images,
 static int entropy_encode_common(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, size_t mcus,
                                  const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
                                  size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status,
-                                 bool status_is_clear, const uint8_t* d_chunk_masks = nullptr) {
+                                 bool status_is_clear, const uint8_t* d_chunk_masks = nullptr, bool planar = false) {
     EntropyScratch sc;
     int rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc);
     if (rc) return rc;
     sc.chunk_masks = d_chunk_masks;
+    sc.planar = planar;
     if (!status_is_clear) JEA_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t), ctx->stream));
     launch_entropy_encode(ctx->stream, d_coefs, n_images, mcus, ctx->d_huff, sc, header, header_len, with_eoi, d_out,
                           out_capacity, d_offsets, d_sizes, d_status);
@@ -560,11 +562,12 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
     if ((rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc))) return rc;
     HeaderBytes hb{};
     jea_write_header(hb.b, width, height, lum_q, chr_q);
+    // the coefficients stay inside the library: chunk-planar layout, all-zero chunks not even written
     launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status,
-                      d_masks);
+                      d_masks, true);
     JEA_HIP(ctx, hipGetLastError());
     return entropy_encode_common(ctx, d_coefs, n_images, mcus, hb, JEA_HEADER_BYTES, true, d_out, out_capacity,
-                                 d_offsets, d_sizes, d_status, true, d_masks);
+                                 d_offsets, d_sizes, d_status, true, d_masks, true);
 }
 
 int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,

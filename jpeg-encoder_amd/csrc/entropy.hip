@@ -67,7 +67,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + incl - v;
 }
 
-template <bool kEmit>
+template <bool kEmit, bool kPlanar>
 __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
                                                                  uint32_t n_tiles,
                                                                  const HuffTables* __restrict__ huff,
@@ -84,13 +84,21 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     uint32_t bits = 0;
     if (threadIdx.x < kTileBlocks && b < nbc) {
-        const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
         BlockRegs blk;
-        load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
         const int ch = (int)(b % 3u);
-        // same channel, previous MCU; the chain starts at 0 (encoder.cpp:20) or, in a
+        int prev_dc;
+        // previous DC: same channel, previous MCU; the chain starts at 0 (encoder.cpp:20) or, in a
         // stripe, at the last MCU of the stripe above
-        const int prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
+        if (kPlanar) {
+            const uint32_t n_mcu = nbc / 3u, mcu = b / 3u;
+            const uint4* q = reinterpret_cast<const uint4*>(coefs) + ((size_t)img * 24 + ch) * n_mcu + mcu;
+            load_block_planar(blk, q, (size_t)3 * n_mcu, (uint32_t)chunk_masks[(size_t)img * nbc + b]);
+            prev_dc = (b >= 3) ? (int)*reinterpret_cast<const int16_t*>(q - 1) : (int)st.initial_dc[b];
+        } else {
+            const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
+            load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
+            prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
+        }
         bool ok;
         if (kEmit) {
             SlotSink sink;
@@ -438,7 +446,7 @@ void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, 
                         const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status) {
     const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
-    block_bits_kernel<false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
+    block_bits_kernel<false, false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
         d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status, StripeInfo{}, nullptr);
 }
 
@@ -452,8 +460,13 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const uint32_t n = (uint32_t)n_images;
     const uint32_t eoi = with_eoi ? 1u : 0u;
 
-    block_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                         sc.slots, d_status, StripeInfo{}, sc.chunk_masks);
+    if (sc.planar)
+        block_bits_kernel<true, true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
+                                                                   sc.slots, d_status, StripeInfo{}, sc.chunk_masks);
+    else
+        block_bits_kernel<true, false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16,
+                                                                    sc.tile_bits, sc.slots, d_status, StripeInfo{},
+                                                                    sc.chunk_masks);
 
     if (n == 1 && n_tiles <= kFoldTiles) {
         // One image with few tiles: every workgroup sums the totals of the tiles
@@ -508,7 +521,7 @@ void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, cons
                         const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status) {
     const uint32_t nbc = (uint32_t)(mcus * 3);
     const uint32_t n_tiles = tiles_per_image(mcus);
-    block_bits_kernel<true><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
+    block_bits_kernel<true, false><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
                                                                      sc.slots, d_status, st, sc.chunk_masks);
     ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
     scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);

@@ -35,7 +35,7 @@ namespace {
 constexpr int kMcusPerGroup = 64;
 constexpr int kFdctThreads = 192;
 
-template <bool kFast>
+template <bool kFast, bool kPlanar>
 __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t* __restrict__ rgb, int width,
                                                                   int height, int blocks_w, uint32_t n_mcu,
                                                                   size_t image_bytes, QuantTables q,
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
             fdct_col(row, u, o);
             quantise_col(o, qt, rqt, u, qv);
         }
-        // zig-zag (entropy_encoder.cpp:15-77) and hand-over through LDS
+        // zig-zag (entropy_encoder.cpp:15-77); hand-over through LDS, or, chunk-planar, straight to
+        // memory: the lanes of a wave are consecutive MCUs of one channel, i.e. consecutive 16-byte
+        // elements of a plane, and chunks that are all zero (most, in most pictures) are not stored
+        uint4* plane = reinterpret_cast<uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu + g0 + m;
         uint32_t mask = 0;
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) {
@@ -148,11 +151,17 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
             chunk.y = pack16(qv[kZigzag[8 * k8 + 2]], qv[kZigzag[8 * k8 + 3]]);
             chunk.z = pack16(qv[kZigzag[8 * k8 + 4]], qv[kZigzag[8 * k8 + 5]]);
             chunk.w = pack16(qv[kZigzag[8 * k8 + 6]], qv[kZigzag[8 * k8 + 7]]);
-            mask |= ((chunk.x | chunk.y | chunk.z | chunk.w) != 0 ? 1u : 0u) << k8;
-            *reinterpret_cast<uint4*>(lds_out + j * 128 + ((((uint32_t)k8 + j) & 7u) << 4)) = chunk;
+            const bool nonzero = (chunk.x | chunk.y | chunk.z | chunk.w) != 0;
+            mask |= (nonzero ? 1u : 0u) << k8;
+            if (kPlanar) {
+                if (k8 == 0 || nonzero) plane[(size_t)k8 * 3 * n_mcu] = chunk;
+            } else {
+                *reinterpret_cast<uint4*>(lds_out + j * 128 + ((((uint32_t)k8 + j) & 7u) << 4)) = chunk;
+            }
         }
         if (chunk_masks != nullptr) chunk_masks[((size_t)blockIdx.y * n_mcu + g0) * 3 + j] = (uint8_t)mask;
     }
+    if (kPlanar) return;
     __syncthreads();
 
     // [mcu][channel][64] int16 of this group is one contiguous run in memory
@@ -162,91 +171,6 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
         const uint32_t jj = i >> 3, kk = i & 7u;
         out[i] = *reinterpret_cast<const uint4*>(lds_out + jj * 128 + (((kk + jj) & 7u) << 4));
     }
-}
-
-// Variant with one wave per workgroup and no LDS: lane = MCU, blockIdx.y = channel.
-// Each lane reads its own eight 24-byte row strips (neighbouring lanes read
-// neighbouring strips, so a wave's three loads of a row cover 1536 contiguous
-// bytes) and stores its own 128-byte coefficient block.  Work items are single
-// waves, which the dispatcher balances over the SIMDs far better than 3-wave
-// groups when one image is only a few waves per SIMD.
-template <bool kFast>
-__global__ __launch_bounds__(64) void fdct_quant_wave_kernel(const uint8_t* __restrict__ rgb, int width, int height,
-                                                             int blocks_w, uint32_t n_mcu, size_t image_bytes,
-                                                             QuantTables q, int16_t* __restrict__ coefs,
-                                                             int32_t* __restrict__ status_to_clear,
-                                                             uint8_t* __restrict__ chunk_masks) {
-    if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-        *status_to_clear = 0;
-    const int channel = blockIdx.y;
-    const uint32_t mcu = blockIdx.x * 64u + threadIdx.x;
-    if (mcu >= n_mcu) return;
-    const uint8_t* img = rgb + (size_t)blockIdx.z * image_bytes;
-    const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
-    double ck, ca, cb, cc;
-    colour_constants(channel, ck, ca, cb, cc);
-
-    float row[8][8];
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-        int yy = (int)by * 8 + y;
-        yy = yy < height ? yy : height - 1;  // bottom edge: repeat the last row
-        uint32_t d[6];
-        if (kFast) {
-            const uint2* src = reinterpret_cast<const uint2*>(img + ((size_t)yy * width + bx * 8) * 3);
-            const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
-            d[0] = w0.x; d[1] = w0.y; d[2] = w1.x; d[3] = w1.y; d[4] = w2.x; d[5] = w2.y;
-        } else {
-            // any width: byte gather with the column clamp of block_grid.cpp:20-22
-#pragma unroll
-            for (int i = 0; i < 6; ++i) d[i] = 0;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                int xx = (int)bx * 8 + p;
-                xx = xx < width ? xx : width - 1;
-                const uint8_t* px = img + ((size_t)yy * width + xx) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int byte = 3 * p + c;
-                    d[byte >> 2] |= (uint32_t)px[c] << (8 * (byte & 3));
-                }
-            }
-        }
-        float f[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
-            const double r = (double)((d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu);
-            const double g = (double)((d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu);
-            const double b = (double)((d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu);
-            const float rounded = (float)floor((((ck + ca * r) + cb * g) + cc * b) + 0.5);
-            f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
-        }
-        fdct_row(f, y, row);
-    }
-
-    const float* qt = channel == 0 ? q.lum_t : q.chr_t;
-    const float* rqt = channel == 0 ? q.rlum_t : q.rchr_t;
-    int qv[64];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        float o[8];
-        fdct_col(row, u, o);
-        quantise_col(o, qt, rqt, u, qv);
-    }
-    uint4* out = reinterpret_cast<uint4*>(coefs + (((size_t)blockIdx.z * n_mcu + mcu) * 3 + channel) * 64);
-    uint32_t mask = 0;
-#pragma unroll
-    for (int k8 = 0; k8 < 8; ++k8) {
-        uint4 chunk;
-        chunk.x = pack16(qv[kZigzag[8 * k8 + 0]], qv[kZigzag[8 * k8 + 1]]);
-        chunk.y = pack16(qv[kZigzag[8 * k8 + 2]], qv[kZigzag[8 * k8 + 3]]);
-        chunk.z = pack16(qv[kZigzag[8 * k8 + 4]], qv[kZigzag[8 * k8 + 5]]);
-        chunk.w = pack16(qv[kZigzag[8 * k8 + 6]], qv[kZigzag[8 * k8 + 7]]);
-        mask |= ((chunk.x | chunk.y | chunk.z | chunk.w) != 0 ? 1u : 0u) << k8;
-        out[k8] = chunk;
-    }
-    if (chunk_masks != nullptr) chunk_masks[((size_t)blockIdx.z * n_mcu + mcu) * 3 + channel] = (uint8_t)mask;
 }
 
 // zig-zag position of natural index n
@@ -469,28 +393,22 @@ __global__ void ycbcr_to_rgb_kernel(const uint8_t* __restrict__ ycc, size_t n, u
 }  // namespace
 
 void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
-                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear, uint8_t* d_chunk_masks) {
+                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear, uint8_t* d_chunk_masks,
+                       bool planar) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
     const bool fast = (width % 8 == 0) && ((reinterpret_cast<uintptr_t>(d_rgb) & 7u) == 0);
-#ifdef JEA_K1_WAVE
-    const dim3 wgrid((n_mcu + 63) / 64, 3, (unsigned)n_images);
-    if (fast)
-        fdct_quant_wave_kernel<true><<<wgrid, 64, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                          d_status_to_clear, d_chunk_masks);
-    else
-        fdct_quant_wave_kernel<false><<<wgrid, 64, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                           d_status_to_clear, d_chunk_masks);
-    return;
-#endif
-    if (fast)
-        fdct_quant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                              d_status_to_clear, d_chunk_masks);
-    else
-        fdct_quant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                               d_status_to_clear, d_chunk_masks);
+    planar = planar && d_chunk_masks != nullptr;
+#define JEA_LAUNCH_FDCT(F, P)                                                                                       \
+    fdct_quant_kernel<F, P><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs, \
+                                                          d_status_to_clear, d_chunk_masks)
+    if (fast && planar) JEA_LAUNCH_FDCT(true, true);
+    else if (fast) JEA_LAUNCH_FDCT(true, false);
+    else if (planar) JEA_LAUNCH_FDCT(false, true);
+    else JEA_LAUNCH_FDCT(false, false);
+#undef JEA_LAUNCH_FDCT
 }
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,

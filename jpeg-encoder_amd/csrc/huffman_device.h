@@ -38,6 +38,17 @@ __device__ __forceinline__ void load_block(BlockRegs& r, const int16_t* __restri
     }
 }
 
+// Chunk-planar layout: chunk i of the block is q[i * plane_stride] (16-byte units).
+__device__ __forceinline__ void load_block_planar(BlockRegs& r, const uint4* __restrict__ q, size_t plane_stride,
+                                                  uint32_t chunk_mask) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i == 0 || ((chunk_mask >> i) & 1u)) v = q[(size_t)i * plane_stride];   // chunk 0 is always stored
+        r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
+    }
+}
+
 __device__ __forceinline__ uint32_t bit_width(uint32_t v) { return 32u - (uint32_t)__clz((int)v); }
 
 // Symbol generation for one block-channel, shared by the length pass and the

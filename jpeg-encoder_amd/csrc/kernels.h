@@ -80,6 +80,7 @@ struct StripeInfo {
 struct EntropyScratch {
     uint16_t* len16;        // [n][mcus*3]      bits per block-channel
     const uint8_t* chunk_masks;  // [n][mcus*3] non-zero 16-byte chunks of each block, or null = load everything
+    bool planar;            // coefficients are in the chunk-planar layout (see launch_fdct_quant); needs chunk_masks
     uint32_t* slots;        // [n][n_tiles][kSlotWords][kSlotStride]  per-block bit strings
     uint32_t* tile_bits;    // [n][n_tiles]
     uint64_t* tile_base;    // [n][n_tiles]     exclusive scan of tile_bits within the image
@@ -95,8 +96,13 @@ struct EntropyScratch {
 // d_status_to_clear (may be null): status word of the encode pass this launch opens; the kernel zeroes it.
 // d_chunk_masks (may be null): one byte per block-channel, bit g set iff zig-zag coefficients 8g..8g+7 are not
 // all zero -- lets the entropy pass skip loading the (usually many) all-zero 16-byte chunks.
+// planar (needs d_chunk_masks): instead of [image][mcu][channel][64], 16-byte chunk c (zig-zag positions
+// 8c..8c+7) of block (mcu, channel) of image i goes to 16-byte element ((i * 8 + c) * 3 + channel) * mcus + mcu,
+// and only chunk 0 and the chunks flagged in the mask are written at all -- the entropy pass then touches a
+// fraction of the memory.  Internal to the fused encode path.
 void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
-                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear, uint8_t* d_chunk_masks);
+                       const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear, uint8_t* d_chunk_masks,
+                       bool planar = false);
 
 void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
                         const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status);
