@@ -134,15 +134,17 @@ def main():
 
     # ---- roofline of the fused colour+FDCT+quantise+zigzag kernel, live, on the library's stream ----
     ext = torch.cuda.ExternalStream(ctx.stream_handle, device=dev)
+    # the variant the fused encode runs: chunk-planar coefficients, all-zero chunks not stored
     d_coefs = torch.empty(args.batch * binding.n_mcu(W, H) * 192, dtype=torch.int16, device=dev)
+    d_masks = torch.empty(args.batch * binding.n_mcu(W, H) * 3, dtype=torch.uint8, device=dev)
     reps = 50
     with torch.cuda.stream(ext):
         for _ in range(5):
-            ctx.fdct_quant_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs)
+            ctx.fdct_quant_planar_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs, d_masks)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ctx.fdct_quant_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs)
+            ctx.fdct_quant_planar_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs, d_masks)
         e1.record()
     ctx.synchronize()
     k1_ms = e0.elapsed_time(e1) / reps
@@ -155,18 +157,19 @@ def main():
     if args.batch * W * H <= 64 << 20:
         d_rgb4 = d_rgb.repeat(4)
         d_coefs4 = torch.empty(4 * d_coefs.numel(), dtype=torch.int16, device=dev)
+        d_masks4 = torch.empty(4 * d_masks.numel(), dtype=torch.uint8, device=dev)
         with torch.cuda.stream(ext):
             for _ in range(3):
-                ctx.fdct_quant_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4)
+                ctx.fdct_quant_planar_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4, d_masks4)
             e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e2.record()
             for _ in range(20):
-                ctx.fdct_quant_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4)
+                ctx.fdct_quant_planar_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4, d_masks4)
             e3.record()
         ctx.synchronize()
         k4_ms = e2.elapsed_time(e3) / 20
         steady = max((k4_ms - k1_ms) / 3, 1e-6)
-        del d_rgb4, d_coefs4
+        del d_rgb4, d_coefs4, d_masks4
     # HBM bytes per launch from the PMC counters, collected in separate rocprofv3 passes on this same command
     # and corrected for gfx950 as profiles/r01_pmc_traffic.json describes; only valid for the workload it was taken on
     traffic = None

@@ -164,6 +164,18 @@ int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t
 int jea_fdct_quant_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
                          const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs);
 
+/* The same transform as the fused encode path runs it (same reference lines): the
+ * coefficients go out in the library's chunk-planar layout -- the 16-byte chunk c
+ * (zig-zag positions 8c..8c+7) of block (mcu, channel) of image i is 16-byte element
+ * ((i * 8 + c) * 3 + channel) * mcus + mcu of d_coefs_planar -- and only chunk 0 and
+ * the chunks that hold a non-zero coefficient are written; d_chunk_masks
+ * ([image][mcu][channel], one byte each) has bit c set for exactly those non-zero
+ * chunks.  Unwritten chunks keep whatever the buffer held.  Asynchronous, like
+ * jea_fdct_quant_async.  d_coefs_planar: n_images * mcus * 3 * 64 int16. */
+int jea_fdct_quant_planar_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width,
+                                uint16_t height, const uint16_t lum_q[64], const uint16_t chr_q[64],
+                                int16_t* d_coefs_planar, uint8_t* d_chunk_masks);
+
 /* Bit length of every block-channel ([image][mcu][channel] order) with the DC
  * prediction chain of encoder.cpp:20 restarted per image.  Replaces
  * entropy_encoder.cpp:94-120 and the length side of :715-765.

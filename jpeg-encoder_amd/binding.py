@@ -17,7 +17,7 @@ EXPORTS = [
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
     "jea_decode_batch", "jea_decode_host",
-    "jea_fdct_quant", "jea_fdct_quant_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
+    "jea_fdct_quant", "jea_fdct_quant_async", "jea_fdct_quant_planar_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
     "jea_rgb_to_ycbcr", "jea_ycbcr_to_rgb",
     "jea_rgb_to_ycbcr_host", "jea_ycbcr_to_rgb_host", "jea_dct_forward_blocks", "jea_dct_inverse_blocks",
     "jea_quantise_blocks", "jea_dequantise_blocks", "jea_huffman_encode_blocks", "jea_stream_upload",
@@ -72,6 +72,7 @@ def load_library():
     lib.jea_decode_host.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_fdct_quant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_fdct_quant_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_fdct_quant_planar_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, vp]
     lib.jea_block_bit_lengths.argtypes = [vp, vp, sz, sz, vp]
     lib.jea_entropy_encode.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp]
     lib.jea_entropy_decode.argtypes = [vp, vp, vp, vp, sz, sz, vp]
@@ -183,6 +184,11 @@ class Context:
     def fdct_quant_async(self, d_rgb, n_images, w, h, lum, chrom, d_coefs):
         self._check(self.lib.jea_fdct_quant_async(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
                                                   chrom.ctypes.data, d_coefs.data_ptr()))
+
+    def fdct_quant_planar_async(self, d_rgb, n_images, w, h, lum, chrom, d_coefs_planar, d_masks):
+        self._check(self.lib.jea_fdct_quant_planar_async(self.handle, d_rgb.data_ptr(), n_images, w, h,
+                                                         lum.ctypes.data, chrom.ctypes.data, d_coefs_planar.data_ptr(),
+                                                         d_masks.data_ptr()))
 
     def idct_dequant(self, d_coefs, n_images, w, h, lum, chrom):
         rgb = self.empty(n_images * 3 * w * h, self.torch.uint8)

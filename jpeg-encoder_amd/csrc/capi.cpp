@@ -442,6 +442,20 @@ int jea_fdct_quant_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, ui
     return JEA_OK;
 }
 
+int jea_fdct_quant_planar_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width,
+                                uint16_t height, const uint16_t lum_q[64], const uint16_t chr_q[64],
+                                int16_t* d_coefs_planar, uint8_t* d_chunk_masks) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb || !d_coefs_planar || !d_chunk_masks || n_images == 0 || n_images > 65535 ||
+        !valid_dims(width, height) || !tables_ok(lum_q, chr_q))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_fdct_quant_planar_async: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs_planar,
+                      nullptr, d_chunk_masks, true);
+    JEA_HIP(ctx, hipGetLastError());
+    return JEA_OK;
+}
+
 int jea_fdct_quant(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
                    const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs) {
     const int rc = jea_fdct_quant_async(ctx, d_rgb, n_images, width, height, lum_q, chr_q, d_coefs);

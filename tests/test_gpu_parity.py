@@ -51,6 +51,33 @@ def test_fdct_quant_matches_oracle(ctx, po, jea, w, h, quality):
         assert np.array_equal(got, want), (name, w, h, quality)
 
 
+@pytest.mark.parametrize("w,h,quality", [(64, 48, 75), (200, 120, 50), (13, 7, 100), (520, 333, 90)])
+def test_fdct_quant_planar_layout(ctx, po, jea, w, h, quality):
+    """The chunk-planar output of the fused path: masks flag exactly the non-zero chunks, chunk 0 and the
+    flagged chunks hold the oracle's coefficients, nothing else is written."""
+    lum, chrom = jea.binding.quant_tables(quality)
+    n = 2
+    imgs = [po.gen_image(w, h, i, 11 + i) for i in range(n)]
+    m = po.n_mcu(w, h)
+    d_rgb = ctx.to_device(np.concatenate([im.reshape(-1) for im in imgs]))
+    fill = 0x7b7b
+    d_coefs = ctx.torch.full((n * m * 192,), fill, dtype=ctx.torch.int16, device=ctx.tdev)
+    d_masks = ctx.torch.zeros(n * m * 3, dtype=ctx.torch.uint8, device=ctx.tdev)
+    ctx.fdct_quant_planar_async(d_rgb, n, w, h, lum, chrom, d_coefs, d_masks)
+    ctx.synchronize()
+    planar = d_coefs.cpu().numpy().reshape(n, 8, 3, m, 8)
+    masks = d_masks.cpu().numpy().reshape(n, m, 3)
+    for i in range(n):
+        want = po.image_to_coefs(imgs[i], lum, chrom).reshape(m, 3, 8, 8)          # [mcu][ch][chunk][8]
+        nonzero = (want != 0).any(-1)                                                # [mcu][ch][chunk]
+        want_mask = (nonzero * (1 << np.arange(8))).sum(-1).astype(np.uint8)
+        assert np.array_equal(masks[i], want_mask)
+        got = planar[i].transpose(2, 1, 0, 3)                                        # [mcu][ch][chunk][8]
+        stored = nonzero.copy(); stored[:, :, 0] = True
+        assert np.array_equal(got[stored], want[stored])
+        assert (got[~stored] == fill).all()
+
+
 def test_fdct_quant_extreme_blocks(ctx, po, jea):
     """Saturated patterns: checkerboards and stripes in pure colours give the largest coefficients."""
     lum, chrom = jea.binding.quant_tables(100)
