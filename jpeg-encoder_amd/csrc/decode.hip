@@ -215,7 +215,8 @@ struct WriteTarget {
     int16_t* out;            // coefficients of this image
     uint32_t block;          // index of the block the start state is in
     uint32_t total_blocks;
-    int last[3];             // running DC per channel at the start state
+    int last0, last1, last2; // running DC per channel at the start state (separate words: an indexed
+                             // array would be forced into scratch memory)
     bool error;              // a malformed symbol was met before the last block ended
     bool finished;           // this walk completed the image's last block ...
     uint32_t final_bit;      // ... at this bit position (relative to the group)
@@ -233,6 +234,13 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
     uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
     const uint32_t end = (sub + 1) * kSubBits;
     int nb = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    // the write pass's running values live in locals (registers) for the length of the walk
+    int16_t* const out = kWrite ? wt->out : nullptr;
+    const uint32_t total_blocks = kWrite ? wt->total_blocks : 0u;
+    uint32_t block = kWrite ? wt->block : 0u;
+    int last0 = kWrite ? wt->last0 : 0, last1 = kWrite ? wt->last1 : 0, last2 = kWrite ? wt->last2 : 0;
+    bool error = false, finished = false;
+    uint32_t final_bit = 0;
     uint32_t wi = p >> 5;
     uint32_t hi = gw.at(wi), lo = gw.at(wi + 1);
     while (p < end) {
@@ -250,7 +258,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
         const uint32_t ss = is_dc ? sym : (sym & 15u);     // amplitude bits that follow the code word
         const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
         if (bad) {
-            if (kWrite) wt->error = true;
+            if (kWrite) error = true;
             p += 1;
             continue;
         }
@@ -263,9 +271,12 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
             dc2 += (c == 2) ? diff : 0;
             if (kWrite) {
                 // entropy_encoder.cpp:125-126: the DC chain runs in int16
-                const int dc = (int)(int16_t)(wt->last[c] + diff);
-                wt->last[c] = dc;
-                if (dc != 0) wt->out[(size_t)wt->block * 64] = (int16_t)dc;
+                const int prev = c == 0 ? last0 : (c == 1 ? last1 : last2);
+                const int dc = (int)(int16_t)(prev + diff);
+                last0 = c == 0 ? dc : last0;
+                last1 = c == 1 ? dc : last1;
+                last2 = c == 2 ? dc : last2;
+                if (dc != 0) out[(size_t)block * 64] = (int16_t)dc;
             }
             z = 1;
         } else {
@@ -273,10 +284,10 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
             if (sym == 0x00 || processed >= 63) {
                 // EOB, or the block is full: then this entry, being the last, is dropped
                 // (entropy_encoder.cpp:129); more than 63 is a stream error for the serial decoder
-                if (kWrite && sym != 0x00 && processed > 63) wt->error = true;
+                if (kWrite && sym != 0x00 && processed > 63) error = true;
                 block_done = true;
             } else {
-                if (kWrite && ss) wt->out[(size_t)wt->block * 64 + processed] = (int16_t)amplitude(v, len, ss);
+                if (kWrite && ss) out[(size_t)block * 64 + processed] = (int16_t)amplitude(v, len, ss);
                 z = processed + 1;
             }
         }
@@ -285,15 +296,20 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
             c = (c == 2) ? 0 : c + 1;
             ++nb;
             if (kWrite) {
-                if (++wt->block == wt->total_blocks) {
-                    wt->finished = true;
-                    wt->final_bit = p;
+                if (++block == total_blocks) {
+                    finished = true;
+                    final_bit = p;
                     break;
                 }
             }
         }
     }
     sums = Sums{nb, dc0, dc1, dc2};
+    if (kWrite) {
+        wt->error = error;
+        wt->finished = finished;
+        wt->final_bit = final_bit;
+    }
     return make_state(p >= end ? p - end : 0, c, z);
 }
 
@@ -473,9 +489,9 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     wt.out = coefs + (size_t)img * total_blocks * 64;
     wt.block = (uint32_t)(gb.x + before.nb);
     wt.total_blocks = total_blocks;
-    wt.last[0] = (int)(int16_t)(gb.y + before.dc0);
-    wt.last[1] = (int)(int16_t)(gb.z + before.dc1);
-    wt.last[2] = (int)(int16_t)(gb.w + before.dc2);
+    wt.last0 = (int)(int16_t)(gb.y + before.dc0);
+    wt.last1 = (int)(int16_t)(gb.z + before.dc1);
+    wt.last2 = (int)(int16_t)(gb.w + before.dc2);
     wt.error = false;
     wt.finished = false;
     wt.final_bit = 0;
