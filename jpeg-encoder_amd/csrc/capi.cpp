@@ -723,7 +723,8 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
 // Uploads the scan ranges (file ranges minus `skip` leading header bytes), sizes the
 // scratch of the parallel decoder and runs it.  Leaves the device status unread.
 static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_t* h_offsets, const uint64_t* h_sizes,
-                              size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs) {
+                              size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs,
+                              uint8_t* d_planar_masks = nullptr) {
     std::vector<uint64_t> seg(3 * n_images);   // offsets | sizes | unstuffed bases
     uint64_t max_size = 0, ubytes = 0;
     bool too_short = false;   // reported after the headers have been looked at, as the reference would
@@ -784,6 +785,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.grp_sum = (int4*)ctx->grp_sum.ptr;
     sc.grp_base = (int4*)ctx->grp_base.ptr;
     sc.changed = (uint32_t*)ctx->round_flags.ptr;
+    sc.out_masks = d_planar_masks;
     JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs,
                                        ctx->d_status));
@@ -815,13 +817,15 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     const size_t mcus = mcus_of(width, height);
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    // the coefficients stay inside the library: chunk-planar layout with chunk masks
+    if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3))) return rc;
     if ((rc = run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,
-                                 (int16_t*)ctx->coefs.ptr)))
+                                 (int16_t*)ctx->coefs.ptr, (uint8_t*)ctx->masks.ptr)))
         return rc;
     // As in the reference, nothing is written to the output when the stream is bad (encoder.cpp:63-70).
     if ((rc = finish_status(ctx, ctx->d_status, "jea_decode_batch"))) return rc;
     launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height,
-                        to_float_tables(lum_q, chr_q), d_rgb);
+                        to_float_tables(lum_q, chr_q), d_rgb, (const uint8_t*)ctx->masks.ptr);
     JEA_HIP(ctx, hipGetLastError());
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JEA_OK;

@@ -177,18 +177,19 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
 // The words of one workgroup's 256 sub-sequences plus one more word, MSB-first
 // values, padded by one word per sub-sequence so that threads reading the same
 // word of their own sub-sequences hit different LDS banks.
-template <uint32_t W>
+template <uint32_t W, uint32_t kTail = 1>
 struct GroupWords {
-    uint32_t w[(kThreads + 1) * (W + 1)];
+    static constexpr uint32_t kWords = kThreads * W + kTail;   // staged stream words
+    uint32_t w[kWords + kWords / W + 1];
     __device__ __forceinline__ uint32_t at(uint32_t wi) const { return w[wi + wi / W]; }
 };
 
 // first_sub: sub-sequence held by the first slot; negative slots (before the stream) read as zero.
-template <uint32_t W>
-__device__ __forceinline__ void stage_group(GroupWords<W>& gw, const uint8_t* __restrict__ stream, uint64_t ulen,
+template <uint32_t W, uint32_t kTail>
+__device__ __forceinline__ void stage_group(GroupWords<W, kTail>& gw, const uint8_t* __restrict__ stream, uint64_t ulen,
                                             int64_t first_sub) {
     const int64_t first_word = first_sub * (int64_t)W;
-    for (uint32_t i = threadIdx.x; i < kThreads * W + 1; i += kThreads) {
+    for (uint32_t i = threadIdx.x; i < GroupWords<W, kTail>::kWords; i += kThreads) {
         const int64_t word = first_word + i;
         const uint64_t byte = (uint64_t)word * 4;
         uint32_t v = 0;
@@ -211,36 +212,18 @@ __device__ __forceinline__ int amplitude(uint32_t v, uint32_t len, uint32_t ssss
     return -(int)(mask & ~bits);
 }
 
-struct WriteTarget {
-    int16_t* out;            // coefficients of this image
-    uint32_t block;          // index of the block the start state is in
-    uint32_t total_blocks;
-    int last0, last1, last2; // running DC per channel at the start state (separate words: an indexed
-                             // array would be forced into scratch memory)
-    bool error;              // a malformed symbol was met before the last block ended
-    bool finished;           // this walk completed the image's last block ...
-    uint32_t final_bit;      // ... at this bit position (relative to the group)
-};
-
 // Decode from `state` (of sub-sequence `sub` of the staged group) to the first
-// symbol boundary at or past the end of the sub-sequence.  Malformed symbols do
-// not stop the walk (one bit is skipped), so that a walk from a wrong guess
-// always ends; on the true chain they are reported through WriteTarget::error.
-template <bool kWrite, uint32_t W>
+// symbol boundary at or past the end of the sub-sequence, counting the blocks
+// completed and summing the DC differences met.  Malformed symbols do not stop
+// the walk (one bit is skipped), so that a walk from a wrong guess always ends.
+template <uint32_t W>
 __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTables& t, uint32_t sub, uint32_t state,
-                                         Sums& sums, WriteTarget* wt) {
+                                         Sums& sums) {
     constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
     uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
     const uint32_t end = (sub + 1) * kSubBits;
     int nb = 0, dc0 = 0, dc1 = 0, dc2 = 0;
-    // the write pass's running values live in locals (registers) for the length of the walk
-    int16_t* const out = kWrite ? wt->out : nullptr;
-    const uint32_t total_blocks = kWrite ? wt->total_blocks : 0u;
-    uint32_t block = kWrite ? wt->block : 0u;
-    int last0 = kWrite ? wt->last0 : 0, last1 = kWrite ? wt->last1 : 0, last2 = kWrite ? wt->last2 : 0;
-    bool error = false, finished = false;
-    uint32_t final_bit = 0;
     uint32_t wi = p >> 5;
     uint32_t hi = gw.at(wi), lo = gw.at(wi + 1);
     while (p < end) {
@@ -258,7 +241,6 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
         const uint32_t ss = is_dc ? sym : (sym & 15u);     // amplitude bits that follow the code word
         const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
         if (bad) {
-            if (kWrite) error = true;
             p += 1;
             continue;
         }
@@ -269,14 +251,162 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
             dc0 += (c == 0) ? diff : 0;
             dc1 += (c == 1) ? diff : 0;
             dc2 += (c == 2) ? diff : 0;
-            if (kWrite) {
+            z = 1;
+        } else {
+            const uint32_t processed = z + (sym >> 4);   // AC positions consumed including this entry
+            if (sym == 0x00 || processed >= 63) block_done = true;
+            else z = processed + 1;
+        }
+        if (block_done) {
+            z = 0;
+            c = (c == 2) ? 0 : c + 1;
+            ++nb;
+        }
+    }
+    sums = Sums{nb, dc0, dc1, dc2};
+    return make_state(p >= end ? p - end : 0, c, z);
+}
+
+// ---------------------------------------------------------------------------
+// Write pass.  A block belongs to the thread in whose sub-sequence it STARTS; that
+// thread decodes it to its end, also past the end of the sub-sequence (at most
+// 1660 bits, which the staged window covers), and the thread after it skips the
+// part it finds itself in.  So every block is produced by exactly one thread,
+// which assembles it in registers 16 bytes (8 zig-zag positions) at a time and
+// stores whole chunks: no zero-filled output is needed and no two threads ever
+// write to the same block.
+//
+// Output layouts: kPlanar = false: [block][64] int16, all eight chunks of every
+// block are stored.  kPlanar = true (inside the library): chunk c of block
+// (mcu, channel) is 16-byte element (c * 3 + channel) * mcus + mcu of the image's
+// coefficient area; chunk 0 and the chunks with a non-zero coefficient are
+// stored, and one mask byte per block says which chunks are non-zero.
+// ---------------------------------------------------------------------------
+
+constexpr uint32_t kWriteTail = 56;   // words staged past the group: 1660 bits of overrun + 64 bits of look-ahead
+
+struct WriteTarget {
+    int16_t* out;            // coefficients of this image
+    uint8_t* masks;          // planar: chunk masks of this image
+    uint32_t n_mcu;
+    uint32_t block;          // index of the block the start state is in
+    uint32_t total_blocks;
+    int last0, last1, last2; // running DC per channel at the start state
+    bool error;              // a malformed symbol was met in a block of this thread
+    bool finished;           // this thread completed the image's last block ...
+    uint32_t final_bit;      // ... at this bit position (relative to the group)
+};
+
+template <bool kPlanar>
+struct BlockWriter {
+    uint4* dst;          // chunk 0 of the current block
+    size_t chunk_stride; // in 16-byte units
+    uint8_t* mask_dst;
+    uint32_t a0, a1, a2, a3;   // the chunk being assembled
+    uint32_t chunk;            // its index
+    uint32_t mask;
+
+    __device__ __forceinline__ void begin(const WriteTarget& wt, uint32_t block) {
+        if (kPlanar) {
+            const uint32_t mcu = block / 3u, ch = block - 3u * mcu;
+            dst = reinterpret_cast<uint4*>(wt.out) + (size_t)ch * wt.n_mcu + mcu;
+            chunk_stride = (size_t)3 * wt.n_mcu;
+            mask_dst = wt.masks + block;
+        } else {
+            dst = reinterpret_cast<uint4*>(wt.out) + (size_t)block * 8;
+            chunk_stride = 1;
+        }
+        a0 = a1 = a2 = a3 = 0;
+        chunk = 0;
+        mask = 0;
+    }
+    __device__ __forceinline__ void flush() {
+        const bool nonzero = (a0 | a1 | a2 | a3) != 0;
+        if (!kPlanar || chunk == 0 || nonzero) dst[chunk * chunk_stride] = make_uint4(a0, a1, a2, a3);
+        mask |= (nonzero ? 1u : 0u) << chunk;
+    }
+    // positions arrive in increasing order
+    __device__ __forceinline__ void put(uint32_t position, int value) {
+        const uint32_t c = position >> 3;
+        if (c != chunk) {
+            flush();
+            if (!kPlanar)
+                for (uint32_t i = chunk + 1; i < c; ++i) dst[i] = make_uint4(0, 0, 0, 0);
+            chunk = c;
+            a0 = a1 = a2 = a3 = 0;
+        }
+        const uint32_t v = ((uint32_t)value & 0xffffu) << (16u * (position & 1u));
+        const uint32_t word = (position >> 1) & 3u;
+        a0 |= word == 0 ? v : 0u;
+        a1 |= word == 1 ? v : 0u;
+        a2 |= word == 2 ? v : 0u;
+        a3 |= word == 3 ? v : 0u;
+    }
+    __device__ __forceinline__ void end() {
+        flush();
+        if (kPlanar) {
+            *mask_dst = (uint8_t)mask;
+        } else {
+            for (uint32_t i = chunk + 1; i < 8; ++i) dst[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+};
+
+template <uint32_t W, bool kPlanar>
+__device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw, const DecodeTables& t, uint32_t sub,
+                                             uint32_t state, WriteTarget& wt) {
+    constexpr uint32_t kSubBits = 32 * W;
+    uint32_t p = sub * kSubBits + (state & 0xffu);
+    uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
+    const uint32_t end = (sub + 1) * kSubBits;
+    uint32_t block = wt.block;
+    int last0 = wt.last0, last1 = wt.last1, last2 = wt.last2;
+    bool error = false, finished = false, owning = false;
+    uint32_t final_bit = 0;
+    BlockWriter<kPlanar> bw;
+    uint32_t wi = p >> 5;
+    uint32_t hi = gw.at(wi), lo = gw.at(wi + 1);
+    for (;;) {
+        if (z == 0 && !owning) {
+            // at a block boundary: the block that starts here is this thread's, if it starts in its sub-sequence
+            if (p >= end) break;
+            owning = true;
+            bw.begin(wt, block);
+        }
+        if ((p >> 5) != wi) {
+            wi = p >> 5;
+            hi = gw.at(wi);
+            lo = gw.at(wi + 1);
+        }
+        const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) << (p & 31u) >> 32);
+        const bool is_dc = z == 0;
+        const uint32_t e = huff_entry(t.tab[(c ? 2u : 0u) + (is_dc ? 0u : 1u)], v >> 16);
+        const uint32_t len = e >> 8, sym = e & 0xffu;
+        const uint32_t ss = is_dc ? sym : (sym & 15u);
+        const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
+        if (bad) {
+            // the serial decoder stops here; the owner of the block reports it
+            error |= owning;
+            p += 1;
+            // a damaged stream must not keep a thread walking for ever: give the block up at the window's end
+            if (p >= kThreads * kSubBits + 32 * (kWriteTail - 2)) {
+                if (owning) bw.end();
+                break;
+            }
+            continue;
+        }
+        p += len + ss;
+        bool block_done = false;
+        if (is_dc) {
+            const int diff = ss ? amplitude(v, len, ss) : 0;
+            if (owning) {
                 // entropy_encoder.cpp:125-126: the DC chain runs in int16
                 const int prev = c == 0 ? last0 : (c == 1 ? last1 : last2);
                 const int dc = (int)(int16_t)(prev + diff);
                 last0 = c == 0 ? dc : last0;
                 last1 = c == 1 ? dc : last1;
                 last2 = c == 2 ? dc : last2;
-                if (dc != 0) out[(size_t)block * 64] = (int16_t)dc;
+                bw.put(0, dc);
             }
             z = 1;
         } else {
@@ -284,33 +414,32 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
             if (sym == 0x00 || processed >= 63) {
                 // EOB, or the block is full: then this entry, being the last, is dropped
                 // (entropy_encoder.cpp:129); more than 63 is a stream error for the serial decoder
-                if (kWrite && sym != 0x00 && processed > 63) error = true;
+                if (sym != 0x00 && processed > 63) error |= owning;
                 block_done = true;
             } else {
-                if (kWrite && ss) out[(size_t)block * 64 + processed] = (int16_t)amplitude(v, len, ss);
+                if (ss && owning) bw.put(processed, amplitude(v, len, ss));
                 z = processed + 1;
             }
         }
         if (block_done) {
             z = 0;
             c = (c == 2) ? 0 : c + 1;
-            ++nb;
-            if (kWrite) {
-                if (++block == total_blocks) {
-                    finished = true;
-                    final_bit = p;
-                    break;
-                }
+            if (owning) bw.end();
+            owning = false;
+            if (++block == wt.total_blocks) {
+                finished = true;
+                final_bit = p;
+                break;
             }
         }
+        if (p >= kThreads * kSubBits + 32 * (kWriteTail - 2)) {   // cannot happen in a well-formed stream
+            if (owning) { bw.end(); error = true; }
+            break;
+        }
     }
-    sums = Sums{nb, dc0, dc1, dc2};
-    if (kWrite) {
-        wt->error = error;
-        wt->finished = finished;
-        wt->final_bit = final_bit;
-    }
-    return make_state(p >= end ? p - end : 0, c, z);
+    wt.error = error;
+    wt.finished = finished;
+    wt.final_bit = final_bit;
 }
 
 template <uint32_t W>
@@ -385,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         const uint32_t start = ends[tid];
         const bool redo = active && start != used;
         if (redo) {
-            my_end = walk<false, W>(gw, t, tid, start, sums, nullptr);
+            my_end = walk<W>(gw, t, tid, start, sums);
             used = start;
             dirty = true;
         }
@@ -449,7 +578,7 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
     if (threadIdx.x == 0 && (uint32_t)carry_s.nb < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
 }
 
-template <uint32_t W>
+template <uint32_t W, bool kPlanar>
 __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* __restrict__ ustream,
                                                                 const uint64_t* __restrict__ ubase,
                                                                 const uint64_t* __restrict__ sizes,
@@ -460,9 +589,10 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const int4* __restrict__ sub_info,
                                                                 const int4* __restrict__ grp_base,
                                                                 int16_t* __restrict__ coefs,
+                                                                uint8_t* __restrict__ masks,
                                                                 int32_t* __restrict__ status) {
     constexpr uint32_t kSubBits = 32 * W;
-    __shared__ GroupWords<W> gw;
+    __shared__ GroupWords<W, kWriteTail> gw;
     __shared__ DecodeTables t;
     __shared__ Sums lds4[4];
 
@@ -487,6 +617,8 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     const Sums before = block_exclusive_scan(Sums{si.x, si.y, si.z, si.w}, lds4, total);   // also orders the staging
     WriteTarget wt;
     wt.out = coefs + (size_t)img * total_blocks * 64;
+    wt.masks = kPlanar ? masks + (size_t)img * total_blocks : nullptr;
+    wt.n_mcu = total_blocks / 3u;
     wt.block = (uint32_t)(gb.x + before.nb);
     wt.total_blocks = total_blocks;
     wt.last0 = (int)(int16_t)(gb.y + before.dc0);
@@ -497,8 +629,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     wt.final_bit = 0;
     if (!active || wt.block >= total_blocks) return;
 
-    Sums sums;
-    (void)walk<true, W>(gw, t, tid, sub_used[sub_index], sums, &wt);
+    write_blocks<W, kPlanar>(gw, t, tid, sub_used[sub_index], wt);
     if (wt.error) {
         // a malformed symbol outranks a missing end marker, as in the serial order of checks
         const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
@@ -610,9 +741,15 @@ hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& 
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     }
     scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base, d_status);
-    decode_write_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
-                                                      p.total_blocks, d_tables, sc.sub_used, sc.sub_info, sc.grp_base,
-                                                      d_coefs, d_status);
+    if (sc.out_masks != nullptr)
+        decode_write_kernel<W, true><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
+                                                                p.n_groups, p.total_blocks, d_tables, sc.sub_used,
+                                                                sc.sub_info, sc.grp_base, d_coefs, sc.out_masks,
+                                                                d_status);
+    else
+        decode_write_kernel<W, false><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
+                                                                 p.n_groups, p.total_blocks, d_tables, sc.sub_used,
+                                                                 sc.sub_info, sc.grp_base, d_coefs, nullptr, d_status);
     return hipGetLastError();
 }
 }  // namespace
@@ -627,8 +764,6 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
     unstuff_compact_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_base, sc.ubase,
                                                       sc.ustream);
     if ((e = hipMemsetAsync(sc.changed, 0, 4 * sizeof(uint32_t), s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(d_coefs, 0, (size_t)p.n_images * p.total_blocks * 64 * sizeof(int16_t), s)) != hipSuccess)
-        return e;
     switch (p.sub_words) {
         case kSubWordsSmall: return run_decode<kSubWordsSmall>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);
         case kSubWordsMedium: return run_decode<kSubWordsMedium>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);

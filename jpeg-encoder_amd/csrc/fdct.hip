@@ -242,7 +242,9 @@ __device__ __forceinline__ void idct_cols(const float (&tmp)[8][8], uint8_t* __r
 // channels of the MCUs meet in LDS, then each thread colour-converts whole pixels.
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_t* __restrict__ coefs, int width,
+template <bool kPlanar>
+__global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_t* __restrict__ coefs,
+                                                                    const uint8_t* __restrict__ chunk_masks, int width,
                                                                     int height, int blocks_w, uint32_t n_mcu,
                                                                     size_t image_bytes, QuantTables q,
                                                                     uint8_t* __restrict__ rgb) {
@@ -256,13 +258,15 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
     const uint32_t mcus_here = (n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup;
 
-    const uint4* in = reinterpret_cast<const uint4*>(coefs + ((size_t)blockIdx.y * n_mcu + g0) * 192);
-    const uint32_t n_chunks = mcus_here * 3 * 8;
-    for (uint32_t i = tid; i < n_chunks; i += kFdctThreads) {
-        const uint32_t jj = i >> 3, kk = i & 7u;
-        *reinterpret_cast<uint4*>(lds_coef + jj * 128 + (((kk + jj) & 7u) << 4)) = in[i];
+    if (!kPlanar) {
+        const uint4* in = reinterpret_cast<const uint4*>(coefs + ((size_t)blockIdx.y * n_mcu + g0) * 192);
+        const uint32_t n_chunks = mcus_here * 3 * 8;
+        for (uint32_t i = tid; i < n_chunks; i += kFdctThreads) {
+            const uint32_t jj = i >> 3, kk = i & 7u;
+            *reinterpret_cast<uint4*>(lds_coef + jj * 128 + (((kk + jj) & 7u) << 4)) = in[i];
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const int channel = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = tid & 63;
@@ -277,13 +281,37 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
         for (int c = 0; c < 8; ++c) chunk[c] = lds_coef + j * 128 + ((((uint32_t)c + j) & 7u) << 4);
         // How far do the non-zero coefficients of this wave's 64 blocks reach along the zig-zag?
         // The transform is then run on the smallest triangle u + v <= D that holds them all.
-        uint32_t rest = 0;
+        bool rest_nonzero;
+        if (kPlanar) {
+            // Chunk-planar input: each thread fetches the chunks of its own block (the lanes of a wave
+            // are consecutive 16-byte elements of a plane) into its LDS slot; the masks say which
+            // chunks exist, and chunks beyond the first are not even copied when the whole wave has none.
+            const uint32_t mcu = g0 + (uint32_t)m;
+            const uint32_t mask = chunk_masks[((size_t)blockIdx.y * n_mcu + mcu) * 3 + channel];
+            const uint4* plane = reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu + mcu;
+            rest_nonzero = (mask >> 1) != 0;
+            *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[0])) = plane[0];
+            if (__ballot(rest_nonzero) != 0) {
 #pragma unroll
-        for (int c = 1; c < 8; ++c) {
-            const uint4 c4 = *reinterpret_cast<const uint4*>(chunk[c]);
-            rest |= c4.x | c4.y | c4.z | c4.w;
+                for (int c = 1; c < 8; ++c) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if ((mask >> c) & 1u) v = plane[(size_t)c * 3 * n_mcu];
+                    *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[c])) = v;
+                }
+            } else {
+                // the widest of the small variants (u + v <= 3) reaches zig-zag positions 8 and 9
+                *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[1])) = make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            uint32_t rest = 0;
+#pragma unroll
+            for (int c = 1; c < 8; ++c) {
+                const uint4 c4 = *reinterpret_cast<const uint4*>(chunk[c]);
+                rest |= c4.x | c4.y | c4.z | c4.w;
+            }
+            rest_nonzero = rest != 0;
         }
-        if (__ballot(rest != 0) == 0) {
+        if (__ballot(rest_nonzero) == 0) {
             // words of the first chunk: zig-zag positions 0-1 | 2-3 | 4-5 | 6-7, which lie on the
             // diagonals u + v = 0,1 | 1,2 | 2,2 | 3,3
             const uint4 c0 = *reinterpret_cast<const uint4*>(chunk[0]);
@@ -412,12 +440,17 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
 }
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
-                         const QuantTables& q, uint8_t* d_rgb) {
+                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
-    idct_dequant_kernel<<<grid, kFdctThreads, 0, s>>>(d_coefs, width, height, bw, n_mcu, image_bytes, q, d_rgb);
+    if (d_chunk_masks != nullptr)
+        idct_dequant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_coefs, d_chunk_masks, width, height, bw, n_mcu,
+                                                                image_bytes, q, d_rgb);
+    else
+        idct_dequant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_coefs, nullptr, width, height, bw, n_mcu,
+                                                                 image_bytes, q, d_rgb);
 }
 
 void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc) {

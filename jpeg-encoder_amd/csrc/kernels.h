@@ -149,11 +149,14 @@ struct DecodeScratch {
     int4* grp_sum;           // [n][n_groups]
     int4* grp_base;          // [n][n_groups] exclusive scan
     uint32_t* changed;       // [4] round flags
+    uint8_t* out_masks;      // null: coefficients go out as [block][64]; else they go out chunk-planar (as
+                             // launch_fdct_quant describes it) and this receives [n][mcus*3] chunk masks
 };
 
 // Enqueues the whole decode and, unlike the other launchers, waits on the stream
 // between synchronisation rounds (it has to read back whether a round changed
-// anything).  d_coefs is overwritten completely; errors go to *d_status.
+// anything).  Every block of d_coefs is written (chunk-planar: chunk 0 and the non-zero chunks);
+// errors go to *d_status.
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
                                  const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status);
@@ -163,8 +166,9 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
 void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
                            uint32_t header_bytes, uint8_t* d_out);
 
+// d_chunk_masks null: d_coefs is [image][mcu][channel][64]; else chunk-planar with these masks.
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
-                         const QuantTables& q, uint8_t* d_rgb);
+                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks = nullptr);
 
 // Per-block (component granularity) launchers, blocks.hip.
 void launch_dct_forward_blocks(hipStream_t s, const uint8_t* d_in, size_t n, float* d_out);
