@@ -179,10 +179,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     return JEA_OK;
 }
 
-int finish_status(jea_ctx* ctx, const int32_t* d_status, const char* what) {
-    int32_t st = 0;
-    JEA_HIP(ctx, hipMemcpyAsync(&st, d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+int report_status(jea_ctx* ctx, int32_t st, const char* what) {
     switch (st) {
         case JEA_OK: return JEA_OK;
         case JEA_ERR_CAPACITY: return fail(ctx, st, std::string(what) + ": output capacity too small");
@@ -191,6 +188,13 @@ int finish_status(jea_ctx* ctx, const int32_t* d_status, const char* what) {
         case JEA_ERR_NO_EOI: return fail(ctx, st, "Failed to find EOI marker");
         default: return fail(ctx, st, std::string(what) + ": device reported status " + std::to_string(st));
     }
+}
+
+int finish_status(jea_ctx* ctx, const int32_t* d_status, const char* what) {
+    int32_t st = 0;
+    JEA_HIP(ctx, hipMemcpyAsync(&st, d_status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return report_status(ctx, st, what);
 }
 
 struct HeaderCheck {
@@ -721,9 +725,9 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
 // ---- decode -------------------------------------------------------------------
 
 // Uploads the scan ranges (file ranges minus `skip` leading header bytes), sizes the
-// scratch of the parallel decoder and runs it.  Leaves the device status unread.
+// scratch of the parallel decoder, runs it and reports the device status under the name `what`.
 static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_t* h_offsets, const uint64_t* h_sizes,
-                              size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs,
+                              size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs, const char* what,
                               uint8_t* d_planar_masks = nullptr) {
     std::vector<uint64_t> seg(3 * n_images);   // offsets | sizes | unstuffed bases
     uint64_t max_size = 0, ubytes = 0;
@@ -787,9 +791,10 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.changed = (uint32_t*)ctx->round_flags.ptr;
     sc.out_masks = d_planar_masks;
     JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    int32_t st = 0;
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs,
-                                       ctx->d_status));
-    return JEA_OK;
+                                       ctx->d_status, &st));
+    return report_status(ctx, st, what);
 }
 
 int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_offsets, const uint64_t* h_sizes,
@@ -799,9 +804,8 @@ int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_of
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_entropy_decode: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
     if (n_images > 65535) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_entropy_decode: more than 65535 images");
-    int rc = run_entropy_decode(ctx, d_scan, h_offsets, h_sizes, n_images, 0, mcus_per_image, d_coefs);
-    if (rc) return rc;
-    return finish_status(ctx, ctx->d_status, "jea_entropy_decode");
+    return run_entropy_decode(ctx, d_scan, h_offsets, h_sizes, n_images, 0, mcus_per_image, d_coefs,
+                              "jea_entropy_decode");
 }
 
 int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offsets, const uint64_t* h_sizes,
@@ -820,10 +824,8 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     // the coefficients stay inside the library: chunk-planar layout with chunk masks
     if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3))) return rc;
     if ((rc = run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,
-                                 (int16_t*)ctx->coefs.ptr, (uint8_t*)ctx->masks.ptr)))
-        return rc;
-    // As in the reference, nothing is written to the output when the stream is bad (encoder.cpp:63-70).
-    if ((rc = finish_status(ctx, ctx->d_status, "jea_decode_batch"))) return rc;
+                                 (int16_t*)ctx->coefs.ptr, "jea_decode_batch", (uint8_t*)ctx->masks.ptr)))
+        return rc;   // as in the reference, nothing is written to the output when the stream is bad (encoder.cpp:63-70)
     launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height,
                         to_float_tables(lum_q, chr_q), d_rgb, (const uint8_t*)ctx->masks.ptr);
     JEA_HIP(ctx, hipGetLastError());

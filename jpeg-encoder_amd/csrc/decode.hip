@@ -716,47 +716,64 @@ DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mc
 namespace {
 template <uint32_t W>
 hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
-                      const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status) {
+                      const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status, int32_t* h_status) {
     hipError_t e;
     const dim3 ggrid(p.n_groups, p.n_images);
+    auto sync_round = [&](int first, uint32_t* flag) {
+        decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
+                                                         d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
+                                                         flag);
+    };
+    auto scan_and_write = [&]() {
+        scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
+                                                           d_status);
+        if (sc.out_masks != nullptr)
+            decode_write_kernel<W, true><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
+                                                                    p.n_groups, p.total_blocks, d_tables, sc.sub_used,
+                                                                    sc.sub_info, sc.grp_base, d_coefs, sc.out_masks,
+                                                                    d_status);
+        else
+            decode_write_kernel<W, false><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
+                                                                     p.n_groups, p.total_blocks, d_tables, sc.sub_used,
+                                                                     sc.sub_info, sc.grp_base, d_coefs, nullptr,
+                                                                     d_status);
+    };
     // Three rounds up front: the first decodes everything, the second repairs the starts of the
     // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.
-    for (int r = 0; r < 3; ++r)
-        decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
-                                                         r == 0 ? 1 : 0, d_tables, sc.sub_end, sc.sub_used,
-                                                         sc.sub_info, sc.grp_sum, sc.changed + r);
+    // The write pass follows at once; whether the third round was indeed idle is read back together
+    // with the status, so the usual decode waits for the GPU only once.
+    sync_round(1, sc.changed + 0);
+    sync_round(0, sc.changed + 1);
+    sync_round(0, sc.changed + 2);
+    scan_and_write();
     uint32_t changed = 0;
     if ((e = hipMemcpyAsync(&changed, sc.changed + 2, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(h_status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    if (changed == 0) return hipGetLastError();
     // Streams that do not re-synchronise within a workgroup's sub-sequences need one more round
-    // per workgroup the error travels through; n_groups rounds always suffice.
+    // per workgroup the error travels through; n_groups rounds always suffice.  What the write pass
+    // produced from the unfinished states (bounded, but meaningless) is then produced again.
     for (uint32_t extra = 0; changed != 0; ++extra) {
         if (extra > p.n_groups + 1) return hipErrorUnknown;
         if ((e = hipMemsetAsync(sc.changed + 3, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
-        decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, 0,
-                                                         d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
-                                                         sc.changed + 3);
+        sync_round(0, sc.changed + 3);
         if ((e = hipMemcpyAsync(&changed, sc.changed + 3, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess)
             return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     }
-    scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base, d_status);
-    if (sc.out_masks != nullptr)
-        decode_write_kernel<W, true><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
-                                                                p.n_groups, p.total_blocks, d_tables, sc.sub_used,
-                                                                sc.sub_info, sc.grp_base, d_coefs, sc.out_masks,
-                                                                d_status);
-    else
-        decode_write_kernel<W, false><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
-                                                                 p.n_groups, p.total_blocks, d_tables, sc.sub_used,
-                                                                 sc.sub_info, sc.grp_base, d_coefs, nullptr, d_status);
+    if ((e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s)) != hipSuccess) return e;
+    scan_and_write();
+    if ((e = hipMemcpyAsync(h_status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     return hipGetLastError();
 }
 }  // namespace
 
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
-                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status) {
+                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 int32_t* h_status) {
     hipError_t e;
     const dim3 cgrid(p.n_chunks, p.n_images);
     unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops);
@@ -765,9 +782,9 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
                                                       sc.ustream);
     if ((e = hipMemsetAsync(sc.changed, 0, 4 * sizeof(uint32_t), s)) != hipSuccess) return e;
     switch (p.sub_words) {
-        case kSubWordsSmall: return run_decode<kSubWordsSmall>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);
-        case kSubWordsMedium: return run_decode<kSubWordsMedium>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);
-        default: return run_decode<kSubWordsLarge>(s, d_sizes, p, sc, d_tables, d_coefs, d_status);
+        case kSubWordsSmall: return run_decode<kSubWordsSmall>(s, d_sizes, p, sc, d_tables, d_coefs, d_status, h_status);
+        case kSubWordsMedium: return run_decode<kSubWordsMedium>(s, d_sizes, p, sc, d_tables, d_coefs, d_status, h_status);
+        default: return run_decode<kSubWordsLarge>(s, d_sizes, p, sc, d_tables, d_coefs, d_status, h_status);
     }
 }
 

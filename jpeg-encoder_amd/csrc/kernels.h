@@ -154,12 +154,12 @@ struct DecodeScratch {
 };
 
 // Enqueues the whole decode and, unlike the other launchers, waits on the stream
-// between synchronisation rounds (it has to read back whether a round changed
-// anything).  Every block of d_coefs is written (chunk-planar: chunk 0 and the non-zero chunks);
+// at the end (it has to read back whether the last synchronisation round changed
+// anything; if so more rounds follow) -- *h_status receives *d_status on that occasion.  Every block of d_coefs is written (chunk-planar: chunk 0 and the non-zero chunks);
 // errors go to *d_status.
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
-                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status);
+                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status, int32_t* h_status);
 
 // Copies the header_bytes bytes in front of each scan (d_scan_offsets[i] is the scan's offset in
 // d_data) to d_out back to back, so that the host can validate all headers with one transfer.
