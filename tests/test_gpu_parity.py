@@ -310,6 +310,22 @@ def test_decode_batches_that_select_longer_subsequences(ctx, po, jea, copies):
         assert np.array_equal(got[i], want[i % 2]), i
 
 
+def test_decode_periodic_streams(ctx, po, jea):
+    """Flat and regularly patterned pictures give streams with a short period, in which a decoder that starts
+    in a wrong state can stay out of phase for ever: the decoder's synchronisation then has to travel from
+    workgroup to workgroup in extra rounds.  The result must not depend on how it got there."""
+    quality = 75
+    lum, chrom = jea.binding.quant_tables(quality)
+    for w, h, kind in [(256, 256, "flat"), (640, 480, "stripes"), (512, 512, "dots"), (1024, 768, "stripes")]:
+        rgb = np.full((h, w, 3), 128, np.uint8)
+        if kind == "stripes":
+            rgb[:, ::16] = 200
+        if kind == "dots":
+            rgb[::8, ::8] = 255
+        jpeg = po.encode(rgb, quality)
+        assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(jpeg, w, h, quality)), (w, h, kind)
+
+
 def test_decode_damaged_streams_agree_with_oracle(ctx, po, jea):
     """A damaged scan either fails in both decoders or decodes to the same picture in both
     (entropy_encoder.cpp:775-777,825-827 and the bounds of :122-144; encoder.cpp:63-65)."""
