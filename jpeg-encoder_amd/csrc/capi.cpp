@@ -44,7 +44,7 @@ struct jea_ctx {
     DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
     // parallel decode
     DeviceBuffer seg_ubase, ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
-        round_flags;
+        round_flags, grp_pending, sub_guess, first_bad, ctx_keys, ctx_vals;
     size_t stream_len = 0;
     // stripe encode in progress (jea_stripe_*)
     size_t stripe_mcus = 0;
@@ -286,7 +286,8 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small,
                             &ctx->seg_ubase, &ctx->ustream, &ctx->chunk_drops, &ctx->chunk_base, &ctx->img_drops,
                             &ctx->sub_end, &ctx->sub_used, &ctx->sub_info, &ctx->grp_sum, &ctx->grp_base,
-                            &ctx->round_flags})
+                            &ctx->round_flags, &ctx->grp_pending, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
+                            &ctx->ctx_vals})
         free_buffer(*b);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_decode) (void)hipFree(ctx->d_decode);
@@ -757,6 +758,12 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     if ((rc = ensure(ctx, ctx->grp_sum, n_images * plan.n_groups * sizeof(int4)))) return rc;
     if ((rc = ensure(ctx, ctx->grp_base, n_images * plan.n_groups * sizeof(int4)))) return rc;
     if ((rc = ensure(ctx, ctx->round_flags, 4 * sizeof(uint32_t)))) return rc;
+    constexpr uint32_t kContextSlots = 1u << 18;
+    if ((rc = ensure(ctx, ctx->grp_pending, n_images * plan.n_groups * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_guess, n_images * subs * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->first_bad, n_images * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ctx_keys, kContextSlots * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->ctx_vals, kContextSlots * sizeof(uint32_t)))) return rc;
     // the vector dies at return: use the blocking copy
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     JEA_HIP(ctx, hipMemcpy(ctx->seg_offsets.ptr, seg.data(), seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -790,6 +797,12 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.grp_base = (int4*)ctx->grp_base.ptr;
     sc.changed = (uint32_t*)ctx->round_flags.ptr;
     sc.out_masks = d_planar_masks;
+    sc.grp_pending = (uint32_t*)ctx->grp_pending.ptr;
+    sc.sub_guess = (uint32_t*)ctx->sub_guess.ptr;
+    sc.first_bad = (uint32_t*)ctx->first_bad.ptr;
+    sc.ctx_keys = (unsigned long long*)ctx->ctx_keys.ptr;
+    sc.ctx_vals = (uint32_t*)ctx->ctx_vals.ptr;
+    sc.ctx_slots = kContextSlots;
     JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
     int32_t st = 0;
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs,

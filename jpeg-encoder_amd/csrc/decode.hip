@@ -26,7 +26,16 @@
 //   decode_write_kernel
 //       one more decode from the now known states, this time with the block
 //       index and the running DC of each channel known at the start of every
-//       sub-sequence, storing the non-zero coefficients into the zeroed output
+//       sub-sequence; every block is stored, in whole 16-byte chunks, by the
+//       thread in whose sub-sequence it starts
+//   context_* kernels (only for streams that do not re-synchronise)
+//       in a stream that repeats with a short period (flat or regularly patterned
+//       pictures) a decoder in a wrong state can stay out of phase for ever, and
+//       the repair would crawl through the stream one sub-sequence at a time.
+//       There, the start states already proven at the head of the stream are
+//       remembered under a hash of the 512 stream bits before them and offered as
+//       guesses to the sub-sequences further on that are preceded by the same
+//       bits; the same fixed-point check decides, so a wrong guess costs time only
 //
 // Run-length removal follows entropy_encoder.cpp:122-144 including its quirk:
 // the last run-length entry of a block is never restored, so a block whose
@@ -442,6 +451,8 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     wt.final_bit = final_bit;
 }
 
+constexpr uint32_t kMaxLocalIterations = 12;   // repair steps per launch; what is left is flagged pending
+
 template <uint32_t W>
 __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __restrict__ ustream,
                                                                const uint64_t* __restrict__ ubase,
@@ -453,6 +464,9 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                uint32_t* __restrict__ sub_used,
                                                                int4* __restrict__ sub_info,
                                                                int4* __restrict__ grp_sum,
+                                                               uint32_t* __restrict__ grp_pending,
+                                                               const uint32_t* __restrict__ sub_guess,
+                                                               const uint32_t* __restrict__ first_bad,
                                                                uint32_t* __restrict__ changed) {
     constexpr uint32_t kSubBits = 32 * W;
     __shared__ GroupWords<W> gw;
@@ -463,36 +477,47 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
     const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const uint64_t ulen = sizes[img] - img_drops[img];
     const uint64_t total_bits = 8 * ulen;
+    const size_t group_index = (size_t)img * n_groups + group;
     if ((uint64_t)group * kOwned * kSubBits >= total_bits) {   // nothing of the stream in this group
-        if (first_round && tid == 0) grp_sum[(size_t)img * n_groups + group] = make_int4(0, 0, 0, 0);
+        if (first_round && tid == 0) {
+            grp_sum[group_index] = make_int4(0, 0, 0, 0);
+            grp_pending[group_index] = 0;
+        }
         return;
     }
     // slot tid holds sub-sequence first_sub + tid; slots below kWarm belong to the previous group
     const int64_t first_sub = (int64_t)group * kOwned - kWarm;
     const int64_t sub = first_sub + tid;
     const bool owned = tid >= kWarm;
-    const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + (tid - kWarm);   // owned slots only
+    const size_t sub_index = group_index * kOwned + (tid - kWarm);   // owned slots only
     const bool in_stream = sub >= 0 && (uint64_t)sub * kSubBits < total_bits;
     const bool active = in_stream && (owned || (first_round && group > 0));
 
-    uint32_t used = kNoState, my_end = 0;
+    uint32_t used = kNoState, my_end = 0, guess = kNoState;
     Sums sums{0, 0, 0, 0};
     if (!first_round) {
-        // The previous round left every group consistent in itself, so only the first owned
-        // sub-sequence can have a new start state: the end state of the group before.
+        // Unless the previous launch ran out of repair steps, it left the group consistent in itself,
+        // and only the first owned sub-sequence can have a new start state: the end state of the
+        // group before.  Guesses from the stream context (see context_guess_kernel) are tried on top.
         uint32_t entry = 0;
         bool need = false;
-        if (tid == kWarm) {
+        if (owned && active) {
             used = sub_used[sub_index];
+            if (sub_guess != nullptr && (uint64_t)sub >= first_bad[img]) {
+                guess = sub_guess[sub_index];
+                if (guess == used) guess = kNoState;
+            }
+            need = guess != kNoState;
+        }
+        if (tid == kWarm) {
             if (group > 0) entry = __atomic_load_n(&sub_end[sub_index - 1], __ATOMIC_RELAXED);
-            need = active && entry != used;
+            need = need || (active && entry != used) || grp_pending[group_index] != 0;
         }
         if (!__syncthreads_or(need ? 1 : 0)) return;
         if (owned) {
             my_end = sub_end[sub_index];
-            used = sub_used[sub_index];
-            const int4 s = sub_info[sub_index];
-            sums = Sums{s.x, s.y, s.z, s.w};
+            const int4 si = sub_info[sub_index];
+            sums = Sums{si.x, si.y, si.z, si.w};
         }
         if (tid == kWarm) ends[kWarm] = entry;
         if (owned) ends[tid + 1] = my_end;
@@ -510,9 +535,25 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
     __syncthreads();
 
     bool dirty = false;
-    for (;;) {
+    if (__syncthreads_or(guess != kNoState ? 1 : 0)) {
+        // offered start states first; the loop below keeps them only where they fit their predecessors
+        if (guess != kNoState) {
+            my_end = walk<W>(gw, t, tid, guess, sums);
+            used = guess;
+            dirty = true;
+        }
+        __syncthreads();
+        if (guess != kNoState) ends[tid + 1] = my_end;
+        __syncthreads();
+    }
+    uint32_t pending = 0;
+    for (uint32_t iteration = 0;; ++iteration) {
         const uint32_t start = ends[tid];
         const bool redo = active && start != used;
+        if (iteration == kMaxLocalIterations) {   // the rest of the repair is left to the next launch
+            pending = __syncthreads_or(redo ? 1 : 0) ? 1u : 0u;
+            break;
+        }
         if (redo) {
             my_end = walk<W>(gw, t, tid, start, sums);
             used = start;
@@ -534,7 +575,8 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         sub_used[sub_index] = kNoState;
         sub_info[sub_index] = make_int4(0, 0, 0, 0);
     }
-    if (any_dirty || first_round) {
+    if (tid == 0) grp_pending[group_index] = pending;
+    if (any_dirty || first_round || pending) {
         Sums v = owned ? sums : Sums{0, 0, 0, 0};
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1)
@@ -542,9 +584,91 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         if ((tid & 63) == 0) red[tid >> 6] = v;
         __syncthreads();
         if (tid == 0) {
-            const Sums s = red[0] + red[1] + red[2] + red[3];
-            grp_sum[(size_t)img * n_groups + group] = make_int4(s.nb, s.dc0, s.dc1, s.dc2);
-            if (any_dirty) atomicOr(changed, 1u);
+            const Sums sm = red[0] + red[1] + red[2] + red[3];
+            grp_sum[group_index] = make_int4(sm.nb, sm.dc0, sm.dc1, sm.dc2);
+            if (any_dirty || pending) atomicOr(changed, 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Guesses from the stream context, for streams that do not re-synchronise.
+// ---------------------------------------------------------------------------
+
+constexpr uint32_t kContextWords = 16;   // stream words before a sub-sequence that identify its context
+
+// first_bad[img] (preset to 0xffffffff) = first sub-sequence that is not proven: the state it was
+// decoded from is not the end state of the one before it (state 0 for the first).  Everything before
+// it has been decoded from the serial decoder's states.
+template <uint32_t W>
+__global__ __launch_bounds__(kThreads) void first_unproven_kernel(const uint64_t* __restrict__ sizes,
+                                                                  const uint64_t* __restrict__ img_drops,
+                                                                  uint32_t n_groups,
+                                                                  const uint32_t* __restrict__ sub_end,
+                                                                  const uint32_t* __restrict__ sub_used,
+                                                                  uint32_t* __restrict__ first_bad) {
+    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    if (tid >= kOwned) return;
+    const uint64_t total_bits = 8 * (sizes[img] - img_drops[img]);
+    const uint64_t sub = (uint64_t)group * kOwned + tid;
+    if (sub * 32 * W >= total_bits) return;
+    const size_t sub_index = (size_t)img * n_groups * kOwned + sub;
+    const uint32_t before = sub == 0 ? 0u : sub_end[sub_index - 1];
+    if (sub_used[sub_index] != before) atomicMin(&first_bad[img], (uint32_t)sub);
+}
+
+__device__ __forceinline__ unsigned long long context_hash(const uint8_t* __restrict__ stream, uint64_t first_word,
+                                                           uint32_t img) {
+    unsigned long long h = 0x9e3779b97f4a7c15ull ^ img;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(stream) + first_word;
+#pragma unroll
+    for (uint32_t i = 0; i < kContextWords; ++i) {
+        h ^= w[i];
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    return h | 1ull;   // 0 marks an empty table entry
+}
+
+// kLearn: the proven sub-sequences (those before first_bad) enter their start state into the table
+// under the hash of the stream words before them.  Otherwise: the others look theirs up.
+template <uint32_t W, bool kLearn>
+__global__ __launch_bounds__(kThreads) void context_kernel(const uint8_t* __restrict__ ustream,
+                                                           const uint64_t* __restrict__ ubase,
+                                                           const uint64_t* __restrict__ sizes,
+                                                           const uint64_t* __restrict__ img_drops,
+                                                           uint32_t n_groups, const uint32_t* __restrict__ first_bad,
+                                                           const uint32_t* __restrict__ sub_used,
+                                                           unsigned long long* __restrict__ keys,
+                                                           uint32_t* __restrict__ vals, uint32_t table_mask,
+                                                           uint32_t* __restrict__ sub_guess) {
+    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    if (tid >= kOwned) return;
+    const uint64_t sub = (uint64_t)group * kOwned + tid;
+    const bool proven = sub < first_bad[img];
+    if (kLearn != proven) return;
+    const uint64_t ulen = sizes[img] - img_drops[img];
+    const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + tid;
+    const uint64_t first_word = sub * W;
+    const bool usable = first_word >= kContextWords && (first_word + 1) * 4 <= ulen;
+    if (!kLearn) sub_guess[sub_index] = kNoState;
+    if (!usable) return;
+    const unsigned long long key = context_hash(ustream + ubase[img], first_word - kContextWords, img);
+    uint32_t slot = (uint32_t)(key >> 20) & table_mask;
+    for (int probe = 0; probe < 8; ++probe, slot = (slot + 1) & table_mask) {
+        if (kLearn) {
+            const unsigned long long old = atomicCAS(&keys[slot], 0ull, key);
+            if (old == 0ull || old == key) {
+                vals[slot] = sub_used[sub_index];
+                return;
+            }
+        } else {
+            const unsigned long long k = keys[slot];
+            if (k == key) {
+                sub_guess[sub_index] = vals[slot];
+                return;
+            }
+            if (k == 0ull) return;
         }
     }
 }
@@ -719,10 +843,11 @@ hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& 
                       const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status, int32_t* h_status) {
     hipError_t e;
     const dim3 ggrid(p.n_groups, p.n_images);
-    auto sync_round = [&](int first, uint32_t* flag) {
+    auto sync_round = [&](int first, uint32_t* flag, bool with_guesses) {
         decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
                                                          d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
-                                                         flag);
+                                                         sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
+                                                         sc.first_bad, flag);
     };
     auto scan_and_write = [&]() {
         scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
@@ -742,22 +867,38 @@ hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& 
     // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.
     // The write pass follows at once; whether the third round was indeed idle is read back together
     // with the status, so the usual decode waits for the GPU only once.
-    sync_round(1, sc.changed + 0);
-    sync_round(0, sc.changed + 1);
-    sync_round(0, sc.changed + 2);
+    sync_round(1, sc.changed + 0, false);
+    sync_round(0, sc.changed + 1, false);
+    sync_round(0, sc.changed + 2, false);
     scan_and_write();
     uint32_t changed = 0;
     if ((e = hipMemcpyAsync(&changed, sc.changed + 2, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(h_status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     if (changed == 0) return hipGetLastError();
-    // Streams that do not re-synchronise within a workgroup's sub-sequences need one more round
-    // per workgroup the error travels through; n_groups rounds always suffice.  What the write pass
-    // produced from the unfinished states (bounded, but meaningless) is then produced again.
-    for (uint32_t extra = 0; changed != 0; ++extra) {
-        if (extra > p.n_groups + 1) return hipErrorUnknown;
+    // The stream does not re-synchronise somewhere.  More rounds follow, each of which extends the
+    // proven head of the stream by at least kMaxLocalIterations sub-sequences; in the first few, the
+    // proven start states are offered as guesses wherever the same 512 stream bits come before
+    // (periodic streams of flat or patterned pictures then settle in a handful of rounds).  What the
+    // write pass produced from the unfinished states (bounded, but meaningless) is produced again.
+    const uint64_t max_rounds = (uint64_t)p.subs_per_image / kMaxLocalIterations + p.n_groups + 8;
+    if ((e = hipMemsetAsync(sc.ctx_keys, 0, (size_t)sc.ctx_slots * sizeof(unsigned long long), s)) != hipSuccess) return e;
+    for (uint64_t extra = 0; changed != 0; ++extra) {
+        if (extra > max_rounds) return hipErrorUnknown;
+        const bool guesses = extra < 64;
+        if (guesses) {
+            if ((e = hipMemsetAsync(sc.first_bad, 0xff, p.n_images * sizeof(uint32_t), s)) != hipSuccess) return e;
+            first_unproven_kernel<W><<<ggrid, kThreads, 0, s>>>(d_sizes, sc.img_drops, p.n_groups, sc.sub_end,
+                                                                sc.sub_used, sc.first_bad);
+            context_kernel<W, true><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                               sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
+                                                               sc.ctx_slots - 1, sc.sub_guess);
+            context_kernel<W, false><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                                sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
+                                                                sc.ctx_slots - 1, sc.sub_guess);
+        }
         if ((e = hipMemsetAsync(sc.changed + 3, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
-        sync_round(0, sc.changed + 3);
+        sync_round(0, sc.changed + 3, guesses);
         if ((e = hipMemcpyAsync(&changed, sc.changed + 3, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess)
             return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;

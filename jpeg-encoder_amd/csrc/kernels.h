@@ -149,6 +149,12 @@ struct DecodeScratch {
     int4* grp_sum;           // [n][n_groups]
     int4* grp_base;          // [n][n_groups] exclusive scan
     uint32_t* changed;       // [4] round flags
+    uint32_t* grp_pending;   // [n][n_groups] workgroup ran out of repair steps in the last round
+    uint32_t* sub_guess;     // [n][subs] start states offered from the stream context
+    uint32_t* first_bad;     // [n] first sub-sequence that is not proven yet
+    unsigned long long* ctx_keys;   // [ctx_slots] context hash table (power-of-two size): keys ...
+    uint32_t* ctx_vals;             // ... and the start states remembered under them
+    uint32_t ctx_slots;
     uint8_t* out_masks;      // null: coefficients go out as [block][64]; else they go out chunk-planar (as
                              // launch_fdct_quant describes it) and this receives [n][mcus*3] chunk masks
 };
