@@ -80,6 +80,19 @@ size_t jea_max_jpeg_bytes(uint16_t width, uint16_t height);
 int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uint16_t* hdr_height,
                      const char** msg);
 
+/* Reads what a file of this format says about itself: the SOF0 dimensions and the
+ * two quantisation tables of its DQT segment (natural order; the segment holds the
+ * 8-bit truncation of each entry in zig-zag order, quantiser.cpp:87-102).  The
+ * reference decoder ignores both (it takes the size from the JPEGImage fields and
+ * the tables from the encoder object, encoder.cpp:46,187-188); with this call a
+ * file can be decoded without knowing the quality it was written with:
+ *   jea_read_header(file, len, &w, &h, lum, chr);  jea_decode_host(ctx, file, len, w, h, lum, chr, rgb);
+ * which equals the reference's decode whenever no table entry exceeded 255 at
+ * encode time.  Fails (JEA_ERR_BAD_HEADER) on what jea_check_header rejects and on
+ * a table entry of 0.  No counterpart in the reference. */
+int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
+                    uint16_t chr_q[64]);
+
 /* ---- whole encode: Encoder::encode, encoder.cpp:14-42 ------------------ */
 
 /* Encodes `n_images` equally sized device-resident images in one pass and

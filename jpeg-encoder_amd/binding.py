@@ -13,7 +13,7 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "HIP", 3: "CAPACITY", 4: "RANGE", 5: "BAD_HEAD
 
 EXPORTS = [
     "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_get_stream", "jea_synchronize",
-    "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header",
+    "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
     "jea_decode_batch", "jea_decode_host",
@@ -62,6 +62,7 @@ def load_library():
     lib.jea_max_jpeg_bytes.argtypes = [u16, u16]
     lib.jea_max_jpeg_bytes.restype = sz
     lib.jea_check_header.argtypes = [vp, sz, c.POINTER(u16), c.POINTER(u16), c.POINTER(c.c_char_p)]
+    lib.jea_read_header.argtypes = [vp, sz, c.POINTER(u16), c.POINTER(u16), vp, vp]
     lib.jea_encode_batch.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp]
     lib.jea_encode_batch_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
     lib.jea_encode_host.argtypes = [vp, vp, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
@@ -122,6 +123,19 @@ def check_header(jpeg):
     w, h, msg = ctypes.c_uint16(0), ctypes.c_uint16(0), ctypes.c_char_p()
     rc = lib.jea_check_header(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(msg))
     return rc == 0, (msg.value.decode() if msg.value else None), w.value, h.value
+
+
+def read_header(jpeg):
+    """(width, height, lum_q, chr_q) as the file states them; raises JeaError on a header the library rejects."""
+    lib = load_library()
+    buf = np.frombuffer(jpeg, np.uint8)
+    w, h = ctypes.c_uint16(0), ctypes.c_uint16(0)
+    lum, chrom = np.zeros(64, np.uint16), np.zeros(64, np.uint16)
+    rc = lib.jea_read_header(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), lum.ctypes.data,
+                             chrom.ctypes.data)
+    if rc:
+        raise JeaError(rc, "jea_read_header: not a file of this format")
+    return w.value, h.value, lum, chrom
 
 
 def n_mcu(w, h):

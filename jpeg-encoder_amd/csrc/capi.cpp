@@ -362,6 +362,22 @@ size_t jea_max_jpeg_bytes(uint16_t width, uint16_t height) {
     return JEA_HEADER_BYTES + 2 * ((mcus_of(width, height) * 3 * 1660 + 7) / 8) + 3;
 }
 
+int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
+                    uint16_t chr_q[64]) {
+    if (!width || !height || !lum_q || !chr_q) return JEA_ERR_INVALID_ARG;
+    const int rc = jea_check_header(h_jpeg, len, width, height, nullptr);
+    if (rc) return rc;
+    // DQT segment at byte 20: marker, length, then {table id, 64 entries in zig-zag order} twice
+    const uint8_t* dqt = h_jpeg + 20;
+    if (dqt[0] != 0xFF || dqt[1] != 0xDB || dqt[4] != 0x00 || dqt[4 + 65] != 0x01) return JEA_ERR_BAD_HEADER;
+    for (int k = 0; k < 64; ++k) {
+        lum_q[kZigzag[k]] = dqt[5 + k];
+        chr_q[kZigzag[k]] = dqt[5 + 65 + k];
+        if (dqt[5 + k] == 0 || dqt[5 + 65 + k] == 0) return JEA_ERR_BAD_HEADER;
+    }
+    return JEA_OK;
+}
+
 int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uint16_t* hdr_height,
                      const char** msg) {
     const char* m = nullptr;

@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -67,6 +68,24 @@ def test_check_header_messages(jea, po):
     bad = bytearray(good); bad[30] ^= 0xFF; bad[300] ^= 0xFF
     assert jea.binding.check_header(bytes(bad))[0]
     assert not jea.binding.check_header(bytes(good[:100]))[0]
+
+
+def test_read_header_returns_the_files_own_tables(jea, po):
+    """Dimensions and DQT tables as the file states them (host-only entry point)."""
+    for quality, (w, h) in [(75, (40, 24)), (37, (8, 8)), (100, (13, 7))]:
+        jpeg = po.encode(po.gen_image(w, h, 1, quality), quality)
+        lum, chrom = jea.binding.quant_tables(quality)
+        assert lum.max() <= 255 and chrom.max() <= 255
+        rw, rh, rlum, rchrom = jea.binding.read_header(jpeg)
+        assert (rw, rh) == (w, h) and np.array_equal(rlum, lum) and np.array_equal(rchrom, chrom)
+    # quality 10: entries above 255 are truncated to 8 bits in the file (quantiser.cpp:87-102)
+    lum, chrom = jea.binding.quant_tables(10)
+    jpeg = po.encode(po.gen_image(16, 16, 1, 1), 10)
+    _, _, rlum, _ = jea.binding.read_header(jpeg)
+    assert lum.max() > 255 and np.array_equal(rlum, lum & 0xff)
+    bad = bytearray(jpeg); bad[20 + 4] = 7
+    with pytest.raises(jea.JeaError):
+        jea.binding.read_header(bytes(bad))
 
 
 def test_missing_library_fails_loudly(jea, monkeypatch, tmp_path):

@@ -362,6 +362,14 @@ def test_decode_damaged_streams_agree_with_oracle(ctx, po, jea):
     assert outcomes["both fail"] > 0 and outcomes["both decode"] > 0, outcomes
 
 
+def test_decode_with_the_files_own_header(ctx, po, jea):
+    """jea_read_header + jea_decode_host decode a file without being told size or quality."""
+    for quality, (w, h) in [(60, (200, 120)), (92, (64, 48))]:
+        jpeg = po.encode(po.gen_image(w, h, 0, 9), quality)
+        rw, rh, lum, chrom = jea.binding.read_header(jpeg)
+        assert np.array_equal(ctx.decode_host(jpeg, rw, rh, lum, chrom), po.decode(jpeg, w, h, quality))
+
+
 def test_decode_errors(ctx, po, jea):
     """Error surface of encoder.cpp:63-65,140-283 and entropy_encoder.cpp:776."""
     w, h, quality = 32, 32, 75
