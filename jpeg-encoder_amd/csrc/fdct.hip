@@ -49,7 +49,9 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
     // ([row 0..7][mcu 0..63][8 px * 3 B], 12 KiB), then, after every wave has
     // finished its row pass, the finished blocks ([mcu][channel][128 B] with the
     // 16-byte chunks rotated by the block index, 24 KiB).
-    __shared__ __align__(16) uint8_t lds[kFdctThreads * 128];
+    // (chunk-planar output leaves from registers: only the 12 KiB of pixel rows are needed then,
+    // which leaves LDS for the entropy kernels of other images running beside this one)
+    __shared__ __align__(16) uint8_t lds[kPlanar ? 8 * kMcusPerGroup * 24 : kFdctThreads * 128];
     uint8_t* const lds_in = lds;
     uint8_t* const lds_out = lds;
 
