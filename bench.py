@@ -57,15 +57,25 @@ def main():
     if world != args.gpus:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     dist = None
+    n_devices = torch.cuda.device_count()
+    # One rank per GPU.  JEA_DIST_BACKEND=gloo rehearses the multi-process flow on a box with fewer
+    # GPUs than ranks (ranks then share devices); the measured runs use RCCL ("nccl").
+    backend = os.environ.get("JEA_DIST_BACKEND", "nccl")
+    if backend == "nccl" and local_rank >= n_devices:
+        raise SystemExit("bench: rank %d has no GPU of its own (%d visible)" % (local_rank, n_devices))
+    device_index = local_rank % max(1, n_devices)
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("jpeg-encoder_amd")
     binding = pkg.binding
-    ctxs = [pkg.Context(local_rank) for _ in range(max(1, args.streams))]
+    ctxs = [pkg.Context(device_index) for _ in range(max(1, args.streams))]
     ctx = ctxs[0]
     dev = ctx.tdev
     lum, chrom = binding.quant_tables(QUALITY)
@@ -129,7 +139,8 @@ def main():
     # whole-job throughput: all ranks' pixels over the slowest rank's time
     pixels_per_step = args.batch * W * H
     sharding = importlib.import_module("jpeg-encoder_amd.sharding")
-    rate, elapsed = sharding.job_throughput(args.steps * pixels_per_step, elapsed, dist, dev)
+    rate, elapsed = sharding.job_throughput(args.steps * pixels_per_step, elapsed, dist,
+                                            dev if backend == "nccl" else "cpu")
     value = rate / 1e6
 
     # ---- roofline of the fused colour+FDCT+quantise+zigzag kernel, live, on the library's stream ----
