@@ -26,6 +26,15 @@ if "big" in sys.argv:
     print("16384^2 bytes", len(jpeg), po.fnv(jpeg), "want 5970b2252be8b37d", flush=True)
     dt = t(lambda: ctx.encode_batch(d, 1, w, h, lum, chrom, capacity=cap, d_out=out), 3)
     print("16384^2 encode %.2f ms = %.1f GPix/s" % (dt * 1e3, w * h / dt / 1e9), flush=True)
+    import json
+    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_hashes.json")))
+    rows = rows if isinstance(rows, list) else rows["rows"]
+    want_rgb = [r for r in rows if r["w"] == 16384][0]["rgb_fnv"]
+    dec = ctx.decode_batch(out, [0], [len(jpeg)], w, h, lum, chrom)
+    print("16384^2 decoded rgb hash", po.fnv(dec.cpu().numpy()), "want", want_rgb, flush=True)
+    dt = t(lambda: ctx.decode_batch(out, [0], [len(jpeg)], w, h, lum, chrom), 3)
+    print("16384^2 decode %.2f ms = %.1f GPix/s" % (dt * 1e3, w * h / dt / 1e9), flush=True)
+    del dec
     del d, out
 
 for (w, h, q, mode, n) in [(3840, 2160, 75, 0, 1), (1920, 1080, 50, 0, 64), (1920, 1080, 50, 1, 16)]:
