@@ -66,6 +66,16 @@ int jea_synchronize(jea_ctx* ctx);
 
 /* ---- tables (host-side helpers, no GPU work) -------------------------- */
 
+/* Colour mapper of everything the context does from now on (default JEA_MAPPER_YCBCR):
+ * JEA_MAPPER_YCBCR  RGBToYCbCrMapper, colour_mapping.cpp:44-97 -- what BaselineEncoder uses;
+ * JEA_MAPPER_RGB    RGBToRGBMapper, colour_mapping.cpp:16-42: the three components are R, G, B
+ *                   as they are and all of them use the luminance quantiser and Huffman tables.
+ * The file header does not depend on it (encoder.cpp:74-138 writes the same component table for
+ * any mapper), so only a decoder set to the same mapper reads such a file back. */
+#define JEA_MAPPER_YCBCR 0
+#define JEA_MAPPER_RGB 1
+int jea_set_colour_mapper(jea_ctx* ctx, int mapper);
+
 /* Quality -> tables, the arithmetic of Quantiser::Quantiser (quantiser.cpp:3-55). */
 void jea_quant_tables(int quality, uint16_t lum_q[64], uint16_t chr_q[64]);
 /* The fixed 607-byte header of encoder.cpp:74-138 (+ quantiser.cpp:87-102,

@@ -12,7 +12,7 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "HIP", 3: "CAPACITY", 4: "RANGE", 5: "BAD_HEAD
              7: "NO_EOI", 8: "NO_DEVICE"}
 
 EXPORTS = [
-    "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_get_stream", "jea_synchronize",
+    "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_set_colour_mapper", "jea_get_stream", "jea_synchronize",
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
@@ -52,6 +52,7 @@ def load_library():
     lib.jea_last_error.argtypes = [vp]
     lib.jea_last_error.restype = c.c_char_p
     lib.jea_set_stream.argtypes = [vp, vp]
+    lib.jea_set_colour_mapper.argtypes = [vp, i32]
     lib.jea_get_stream.argtypes = [vp]
     lib.jea_get_stream.restype = vp
     lib.jea_synchronize.argtypes = [vp]
@@ -186,6 +187,10 @@ class Context:
 
     def empty(self, n, dtype):
         return self.torch.empty(int(n), dtype=dtype, device=self.tdev)
+
+    def set_colour_mapper(self, mapper):
+        """0: RGB -> YCbCr (default); 1: RGB pass-through, all components on the luminance tables."""
+        self._check(self.lib.jea_set_colour_mapper(self.handle, int(mapper)))
 
     # ---- stages ----
     def fdct_quant(self, d_rgb, n_images, w, h, lum, chrom):

@@ -38,6 +38,7 @@ struct jea_ctx {
     HuffTables* d_huff = nullptr;
     DecodeTables* d_decode = nullptr;
     int32_t* d_status = nullptr;
+    ComponentMode mode;   // jea_set_colour_mapper
     // scratch, grown on demand and kept
     DeviceBuffer coefs, masks, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
     DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
@@ -166,6 +167,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     sc.len16 = (uint16_t*)ctx->len16.ptr;
     sc.chunk_masks = nullptr;  // set by callers whose coefficients come with masks from the forward kernel
     sc.planar = false;
+    sc.mode = ctx->mode;
     sc.slots = (uint32_t*)ctx->slots.ptr;
     sc.tile_bits = (uint32_t*)ctx->tile_bits.ptr;
     sc.tile_base = (uint64_t*)ctx->tile_base.ptr;
@@ -306,6 +308,14 @@ int jea_set_stream(jea_ctx* ctx, void* hip_stream) {
 }
 
 void* jea_get_stream(jea_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int jea_set_colour_mapper(jea_ctx* ctx, int mapper) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (mapper == JEA_MAPPER_YCBCR) ctx->mode = ComponentMode{1u, 0u};
+    else if (mapper == JEA_MAPPER_RGB) ctx->mode = ComponentMode{7u, 1u};
+    else return fail(ctx, JEA_ERR_INVALID_ARG, "jea_set_colour_mapper: unknown mapper");
+    return JEA_OK;
+}
 
 int jea_synchronize(jea_ctx* ctx) {
     if (!ctx) return JEA_ERR_INVALID_ARG;
@@ -458,7 +468,8 @@ int jea_fdct_quant_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, ui
         !tables_ok(lum_q, chr_q))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_fdct_quant: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
-    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, nullptr, nullptr);
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, nullptr, nullptr,
+                      false, ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
     return JEA_OK;
 }
@@ -472,7 +483,7 @@ int jea_fdct_quant_planar_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_ima
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_fdct_quant_planar_async: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
     launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs_planar,
-                      nullptr, d_chunk_masks, true);
+                      nullptr, d_chunk_masks, true, ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
     return JEA_OK;
 }
@@ -492,7 +503,8 @@ int jea_idct_dequant(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, uint
         !tables_ok(lum_q, chr_q))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_idct_dequant: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
-    launch_idct_dequant(ctx->stream, d_coefs, n_images, width, height, to_float_tables(lum_q, chr_q), d_rgb);
+    launch_idct_dequant(ctx->stream, d_coefs, n_images, width, height, to_float_tables(lum_q, chr_q), d_rgb, nullptr,
+                        ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JEA_OK;
@@ -528,7 +540,7 @@ int jea_block_bit_lengths(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images,
     if ((rc = ensure(ctx, ctx->tile_bits, n_images * tiles_per_image(mcus_per_image) * sizeof(uint32_t)))) return rc;
     JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
     launch_bit_lengths(ctx->stream, d_coefs, n_images, mcus_per_image, ctx->d_huff, d_lengths,
-                       (uint32_t*)ctx->tile_bits.ptr, ctx->d_status);
+                       (uint32_t*)ctx->tile_bits.ptr, ctx->d_status, ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
     return finish_status(ctx, ctx->d_status, "jea_block_bit_lengths");
 }
@@ -599,7 +611,7 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
     jea_write_header(hb.b, width, height, lum_q, chr_q);
     // the coefficients stay inside the library: chunk-planar layout, all-zero chunks not even written
     launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status,
-                      d_masks, true);
+                      d_masks, true, ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
     return entropy_encode_common(ctx, d_coefs, n_images, mcus, hb, JEA_HEADER_BYTES, true, d_out, out_capacity,
                                  d_offsets, d_sizes, d_status, true, d_masks, true);
@@ -665,7 +677,7 @@ int jea_stripe_transform(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t wid
     if ((rc = prepare_entropy_scratch(ctx, 1, mcus, worst, sc))) return rc;
     int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
     launch_fdct_quant(ctx->stream, d_rgb_stripe, 1, width, stripe_height, to_float_tables(lum_q, chr_q), d_coefs,
-                      ctx->d_status, (uint8_t*)ctx->masks.ptr);
+                      ctx->d_status, (uint8_t*)ctx->masks.ptr, false, ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
     for (int ch = 0; ch < 3; ++ch)
         JEA_HIP(ctx, hipMemcpyAsync(&last_dc[ch], d_coefs + ((mcus - 1) * 3 + ch) * 64, sizeof(int16_t),
@@ -813,6 +825,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.grp_base = (int4*)ctx->grp_base.ptr;
     sc.changed = (uint32_t*)ctx->round_flags.ptr;
     sc.out_masks = d_planar_masks;
+    sc.mode = ctx->mode;
     sc.grp_pending = (uint32_t*)ctx->grp_pending.ptr;
     sc.sub_guess = (uint32_t*)ctx->sub_guess.ptr;
     sc.first_bad = (uint32_t*)ctx->first_bad.ptr;
@@ -856,7 +869,7 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
                                  (int16_t*)ctx->coefs.ptr, "jea_decode_batch", (uint8_t*)ctx->masks.ptr)))
         return rc;   // as in the reference, nothing is written to the output when the stream is bad (encoder.cpp:63-70)
     launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height,
-                        to_float_tables(lum_q, chr_q), d_rgb, (const uint8_t*)ctx->masks.ptr);
+                        to_float_tables(lum_q, chr_q), d_rgb, (const uint8_t*)ctx->masks.ptr, ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JEA_OK;

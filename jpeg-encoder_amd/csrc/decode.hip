@@ -226,8 +226,8 @@ __device__ __forceinline__ int amplitude(uint32_t v, uint32_t len, uint32_t ssss
 // completed and summing the DC differences met.  Malformed symbols do not stop
 // the walk (one bit is skipped), so that a walk from a wrong guess always ends.
 template <uint32_t W>
-__device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTables& t, uint32_t sub, uint32_t state,
-                                         Sums& sums) {
+__device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTables& t, uint32_t lum_mask,
+                                         uint32_t sub, uint32_t state, Sums& sums) {
     constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
     uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
@@ -245,7 +245,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
         // One path for DC and AC symbols: the threads of a wave are in different
         // places of their blocks, so separate branches would both run every time.
         const bool is_dc = z == 0;
-        const uint32_t e = huff_entry(t.tab[(c ? 2u : 0u) + (is_dc ? 0u : 1u)], v >> 16);
+        const uint32_t e = huff_entry(t.tab[(((lum_mask >> c) & 1u) ? 0u : 2u) + (is_dc ? 0u : 1u)], v >> 16);
         const uint32_t len = e >> 8, sym = e & 0xffu;
         const uint32_t ss = is_dc ? sym : (sym & 15u);     // amplitude bits that follow the code word
         const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
@@ -362,8 +362,8 @@ struct BlockWriter {
 };
 
 template <uint32_t W, bool kPlanar>
-__device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw, const DecodeTables& t, uint32_t sub,
-                                             uint32_t state, WriteTarget& wt) {
+__device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw, const DecodeTables& t,
+                                             uint32_t lum_mask, uint32_t sub, uint32_t state, WriteTarget& wt) {
     constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
     uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
@@ -389,7 +389,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
         }
         const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) << (p & 31u) >> 32);
         const bool is_dc = z == 0;
-        const uint32_t e = huff_entry(t.tab[(c ? 2u : 0u) + (is_dc ? 0u : 1u)], v >> 16);
+        const uint32_t e = huff_entry(t.tab[(((lum_mask >> c) & 1u) ? 0u : 2u) + (is_dc ? 0u : 1u)], v >> 16);
         const uint32_t len = e >> 8, sym = e & 0xffu;
         const uint32_t ss = is_dc ? sym : (sym & 15u);
         const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                uint32_t* __restrict__ grp_pending,
                                                                const uint32_t* __restrict__ sub_guess,
                                                                const uint32_t* __restrict__ first_bad,
+                                                               uint32_t lum_mask,
                                                                uint32_t* __restrict__ changed) {
     constexpr uint32_t kSubBits = 32 * W;
     __shared__ GroupWords<W> gw;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
     if (__syncthreads_or(guess != kNoState ? 1 : 0)) {
         // offered start states first; the loop below keeps them only where they fit their predecessors
         if (guess != kNoState) {
-            my_end = walk<W>(gw, t, tid, guess, sums);
+            my_end = walk<W>(gw, t, lum_mask, tid, guess, sums);
             used = guess;
             dirty = true;
         }
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
             break;
         }
         if (redo) {
-            my_end = walk<W>(gw, t, tid, start, sums);
+            my_end = walk<W>(gw, t, lum_mask, tid, start, sums);
             used = start;
             dirty = true;
         }
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const int4* __restrict__ sub_info,
                                                                 const int4* __restrict__ grp_base,
                                                                 int16_t* __restrict__ coefs,
-                                                                uint8_t* __restrict__ masks,
+                                                                uint8_t* __restrict__ masks, uint32_t lum_mask,
                                                                 int32_t* __restrict__ status) {
     constexpr uint32_t kSubBits = 32 * W;
     __shared__ GroupWords<W, kWriteTail> gw;
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     wt.final_bit = 0;
     if (!active || wt.block >= total_blocks) return;
 
-    write_blocks<W, kPlanar>(gw, t, tid, sub_used[sub_index], wt);
+    write_blocks<W, kPlanar>(gw, t, lum_mask, tid, sub_used[sub_index], wt);
     if (wt.error) {
         // a malformed symbol outranks a missing end marker, as in the serial order of checks
         const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
@@ -847,7 +848,7 @@ hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& 
         decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
                                                          d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
                                                          sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
-                                                         sc.first_bad, flag);
+                                                         sc.first_bad, sc.mode.lum_mask, flag);
     };
     auto scan_and_write = [&]() {
         scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
@@ -856,12 +857,12 @@ hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& 
             decode_write_kernel<W, true><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
                                                                     p.n_groups, p.total_blocks, d_tables, sc.sub_used,
                                                                     sc.sub_info, sc.grp_base, d_coefs, sc.out_masks,
-                                                                    d_status);
+                                                                    sc.mode.lum_mask, d_status);
         else
             decode_write_kernel<W, false><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
                                                                      p.n_groups, p.total_blocks, d_tables, sc.sub_used,
                                                                      sc.sub_info, sc.grp_base, d_coefs, nullptr,
-                                                                     d_status);
+                                                                     sc.mode.lum_mask, d_status);
     };
     // Three rounds up front: the first decodes everything, the second repairs the starts of the
     // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
                                                                  uint32_t* __restrict__ tile_bits,
                                                                  uint32_t* __restrict__ slots,
                                                                  int32_t* __restrict__ status, StripeInfo st,
-                                                                 const uint8_t* __restrict__ chunk_masks) {
+                                                                 const uint8_t* __restrict__ chunk_masks,
+                                                                 ComponentMode mode) {
     __shared__ HuffLds h;
     __shared__ uint32_t wsum[4];
     load_huff(h, huff);
@@ -100,15 +101,16 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
             prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
         }
         bool ok;
+        const int cls = mode.is_lum((uint32_t)ch) ? 0 : 1;   // Huffman table class (encoder.cpp:25)
         if (kEmit) {
             SlotSink sink;
             sink.slot = slots + ((size_t)img * n_tiles + tile) * kSlotWords * kSlotStride + threadIdx.x;
-            ok = encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
+            ok = encode_block(blk, prev_dc, h.dc[cls], h.ac[cls], sink);
             sink.finish();
             bits = sink.bits;
         } else {
             CountSink sink;
-            ok = encode_block(blk, prev_dc, h.dc[ch ? 1 : 0], h.ac[ch ? 1 : 0], sink);
+            ok = encode_block(blk, prev_dc, h.dc[cls], h.ac[cls], sink);
             bits = sink.bits;
         }
         if (!ok) atomicExch(status, JEA_ERR_RANGE);
@@ -443,11 +445,12 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
 }  // namespace
 
 void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
-                        const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status) {
+                        const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status,
+                        ComponentMode mode) {
     const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
     block_bits_kernel<false, false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
-        d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status, StripeInfo{}, nullptr);
+        d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status, StripeInfo{}, nullptr, mode);
 }
 
 void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -462,11 +465,12 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
 
     if (sc.planar)
         block_bits_kernel<true, true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                                   sc.slots, d_status, StripeInfo{}, sc.chunk_masks);
+                                                                   sc.slots, d_status, StripeInfo{}, sc.chunk_masks,
+                                                                   sc.mode);
     else
         block_bits_kernel<true, false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16,
                                                                     sc.tile_bits, sc.slots, d_status, StripeInfo{},
-                                                                    sc.chunk_masks);
+                                                                    sc.chunk_masks, sc.mode);
 
     if (n == 1 && n_tiles <= kFoldTiles) {
         // One image with few tiles: every workgroup sums the totals of the tiles
@@ -522,7 +526,7 @@ void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, cons
     const uint32_t nbc = (uint32_t)(mcus * 3);
     const uint32_t n_tiles = tiles_per_image(mcus);
     block_bits_kernel<true, false><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                                     sc.slots, d_status, st, sc.chunk_masks);
+                                                                     sc.slots, d_status, st, sc.chunk_masks, sc.mode);
     ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
     scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
     stripe_head_kernel<<<1, 64, 0, s>>>(sc.len16, sc.slots, nbc, d_head);

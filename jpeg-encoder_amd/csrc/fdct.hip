@@ -41,7 +41,8 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
                                                                   size_t image_bytes, QuantTables q,
                                                                   int16_t* __restrict__ coefs,
                                                                   int32_t* __restrict__ status_to_clear,
-                                                                  uint8_t* __restrict__ chunk_masks) {
+                                                                  uint8_t* __restrict__ chunk_masks,
+                                                                  ComponentMode mode) {
     // First kernel of an encode pass: clears the pass's status word so that no
     // separate memset launch is needed (later kernels only ever raise it).
     if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status_to_clear = 0;
@@ -104,36 +105,57 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
         double ck, ca, cb, cc;
         colour_constants(channel, ck, ca, cb, cc);
         const ColourInt ci = colour_int_constants(channel);
+        if (mode.passthrough) {
+            // RGBToRGBMapper (colour_mapping.cpp:16-26): the component as it is.  A loop of its own,
+            // so that the usual path carries no test per pixel.
 #pragma unroll
-        for (int y = 0; y < 8; ++y) {
-            const uint2* src = reinterpret_cast<const uint2*>(lds_in + y * 1536 + m * 24);
-            const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
-            const uint32_t d[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
-            float f[8];
+            for (int y = 0; y < 8; ++y) {
+                const uint2* src = reinterpret_cast<const uint2*>(lds_in + y * 1536 + m * 24);
+                const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
+                const uint32_t d[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                float f[8];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
-                const uint32_t ri = (d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu;
-                const uint32_t gi = (d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu;
-                const uint32_t bi = (d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu;
-                bool tie;
-                f[p] = colour_forward_shifted_fast(ci, (float)ri, (float)gi, (float)bi, tie);
-                if (__builtin_expect(__any(tie), 0)) {
-                    // the literal formula; floor(v + 0.5) is an integer in [-1, 256]: exact as a float, so
-                    // the clamp to [0, 255] (:49-51) can be done there; then "- 128" into int8 (:13-19)
-                    const float rounded =
-                        (float)floor((((ck + ca * (double)ri) + cb * (double)gi) + cc * (double)bi) + 0.5);
-                    f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
+                for (int p = 0; p < 8; ++p) {
+                    const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
+                    const uint32_t ri = (d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu;
+                    const uint32_t gi = (d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu;
+                    const uint32_t bi = (d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu;
+                    f[p] = (float)(channel == 0 ? ri : (channel == 1 ? gi : bi)) - 128.0f;
                 }
+                fdct_row(f, y, row);
             }
-            fdct_row(f, y, row);
+        } else {
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                const uint2* src = reinterpret_cast<const uint2*>(lds_in + y * 1536 + m * 24);
+                const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
+                const uint32_t d[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                float f[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int b0 = 3 * p, b1 = 3 * p + 1, b2 = 3 * p + 2;
+                    const uint32_t ri = (d[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu;
+                    const uint32_t gi = (d[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu;
+                    const uint32_t bi = (d[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu;
+                    bool tie;
+                    f[p] = colour_forward_shifted_fast(ci, (float)ri, (float)gi, (float)bi, tie);
+                    if (__builtin_expect(__any(tie), 0)) {
+                        // the literal formula; floor(v + 0.5) is an integer in [-1, 256]: exact as a float, so
+                        // the clamp to [0, 255] (:49-51) can be done there; then "- 128" into int8 (:13-19)
+                        const float rounded =
+                            (float)floor((((ck + ca * (double)ri) + cb * (double)gi) + cc * (double)bi) + 0.5);
+                        f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
+                    }
+                }
+                fdct_row(f, y, row);
+            }
         }
     }
     __syncthreads();  // every wave is done with lds_in: the buffer becomes lds_out
 
     if (active) {
-        const float* qt = channel == 0 ? q.lum_t : q.chr_t;
-        const float* rqt = channel == 0 ? q.rlum_t : q.rchr_t;
+        const float* qt = mode.is_lum(channel) ? q.lum_t : q.chr_t;
+        const float* rqt = mode.is_lum(channel) ? q.rlum_t : q.rchr_t;
         int qv[64];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -249,7 +271,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
                                                                     const uint8_t* __restrict__ chunk_masks, int width,
                                                                     int height, int blocks_w, uint32_t n_mcu,
                                                                     size_t image_bytes, QuantTables q,
-                                                                    uint8_t* __restrict__ rgb) {
+                                                                    uint8_t* __restrict__ rgb, ComponentMode mode) {
     // coefficients as rotated 16-byte chunks (as in the forward kernel); after the row step the
     // first half is reused for the samples, [channel][mcu][64] u8
     __shared__ __align__(16) uint8_t lds_coef[kFdctThreads * 128];
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     const int m = tid & 63;
     const uint32_t j = (uint32_t)m * 3 + (uint32_t)channel;
     const bool valid = (uint32_t)m < mcus_here;
-    const float* qt = channel == 0 ? q.lum : q.chr;
+    const float* qt = mode.is_lum(channel) ? q.lum : q.chr;
     float tmp[8][8];
     int diag = 7;
     if (valid) {
@@ -357,8 +379,10 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             for (int p = 0; p < 8; ++p) {
                 const int sh = 8 * (p & 3);
                 uint8_t rr, gg, bb;
-                colour_inverse((int)((yy[p >> 2] >> sh) & 0xffu), (int)((cbb[p >> 2] >> sh) & 0xffu),
-                               (int)((crr[p >> 2] >> sh) & 0xffu), rr, gg, bb);
+                const int c0 = (int)((yy[p >> 2] >> sh) & 0xffu), c1 = (int)((cbb[p >> 2] >> sh) & 0xffu),
+                          c2 = (int)((crr[p >> 2] >> sh) & 0xffu);
+                if (mode.passthrough) { rr = (uint8_t)c0; gg = (uint8_t)c1; bb = (uint8_t)c2; }   // colour_mapping.cpp:28-37
+                else colour_inverse(c0, c1, c2, rr, gg, bb);
                 const uint8_t px3[3] = {rr, gg, bb};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -387,7 +411,8 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             const int Cb = lds_px[(1 * kMcusPerGroup + mm) * 64 + r * 8 + p];
             const int Cr = lds_px[(2 * kMcusPerGroup + mm) * 64 + r * 8 + p];
             uint8_t rr, gg, bb;
-            colour_inverse(Y, Cb, Cr, rr, gg, bb);
+            if (mode.passthrough) { rr = (uint8_t)Y; gg = (uint8_t)Cb; bb = (uint8_t)Cr; }
+            else colour_inverse(Y, Cb, Cr, rr, gg, bb);
             uint8_t* dst = img + ((size_t)y * width + x) * 3;
             dst[0] = rr; dst[1] = gg; dst[2] = bb;
         }
@@ -424,7 +449,7 @@ __global__ void ycbcr_to_rgb_kernel(const uint8_t* __restrict__ ycc, size_t n, u
 
 void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
                        const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear, uint8_t* d_chunk_masks,
-                       bool planar) {
+                       bool planar, ComponentMode mode) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
@@ -433,7 +458,7 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
     planar = planar && d_chunk_masks != nullptr;
 #define JEA_LAUNCH_FDCT(F, P)                                                                                       \
     fdct_quant_kernel<F, P><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs, \
-                                                          d_status_to_clear, d_chunk_masks)
+                                                          d_status_to_clear, d_chunk_masks, mode)
     if (fast && planar) JEA_LAUNCH_FDCT(true, true);
     else if (fast) JEA_LAUNCH_FDCT(true, false);
     else if (planar) JEA_LAUNCH_FDCT(false, true);
@@ -442,17 +467,17 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
 }
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
-                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks) {
+                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks, ComponentMode mode) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
     if (d_chunk_masks != nullptr)
         idct_dequant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_coefs, d_chunk_masks, width, height, bw, n_mcu,
-                                                                image_bytes, q, d_rgb);
+                                                                image_bytes, q, d_rgb, mode);
     else
         idct_dequant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_coefs, nullptr, width, height, bw, n_mcu,
-                                                                 image_bytes, q, d_rgb);
+                                                                 image_bytes, q, d_rgb, mode);
 }
 
 void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc) {

@@ -43,6 +43,16 @@ struct DecodeTables {
     DecodeTable tab[4];
 };
 
+// Which of the reference's colour mappers the components come from (colour_mapping.cpp):
+// RGBToYCbCrMapper -- the transform of :44-92, component 0 is the only luminance component (:94-97);
+// RGBToRGBMapper   -- components are R, G, B as they are (:16-37) and all three count as luminance
+//                     (:39-42), i.e. use the luminance quantiser and Huffman tables.
+struct ComponentMode {
+    uint32_t lum_mask = 1;     // bit c set: component c uses the luminance tables
+    uint32_t passthrough = 0;  // non-zero: no colour transform
+    __host__ __device__ bool is_lum(uint32_t c) const { return (lum_mask >> c) & 1u; }
+};
+
 struct HeaderBytes {
     uint8_t b[608];  // 607 used
 };
@@ -81,6 +91,7 @@ struct EntropyScratch {
     uint16_t* len16;        // [n][mcus*3]      bits per block-channel
     const uint8_t* chunk_masks;  // [n][mcus*3] non-zero 16-byte chunks of each block, or null = load everything
     bool planar;            // coefficients are in the chunk-planar layout (see launch_fdct_quant); needs chunk_masks
+    ComponentMode mode;
     uint32_t* slots;        // [n][n_tiles][kSlotWords][kSlotStride]  per-block bit strings
     uint32_t* tile_bits;    // [n][n_tiles]
     uint64_t* tile_base;    // [n][n_tiles]     exclusive scan of tile_bits within the image
@@ -102,10 +113,11 @@ struct EntropyScratch {
 // fraction of the memory.  Internal to the fused encode path.
 void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int width, int height,
                        const QuantTables& q, int16_t* d_coefs, int32_t* d_status_to_clear, uint8_t* d_chunk_masks,
-                       bool planar = false);
+                       bool planar = false, ComponentMode mode = ComponentMode{});
 
 void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
-                        const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status);
+                        const HuffTables* d_huff, uint16_t* d_len16, uint32_t* d_tile_bits, int32_t* d_status,
+                        ComponentMode mode = ComponentMode{});
 
 // bit-length pass -> scans -> pack -> stuff.  header_len is 0 or 607; with_eoi appends FFD9.
 void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -155,6 +167,7 @@ struct DecodeScratch {
     unsigned long long* ctx_keys;   // [ctx_slots] context hash table (power-of-two size): keys ...
     uint32_t* ctx_vals;             // ... and the start states remembered under them
     uint32_t ctx_slots;
+    ComponentMode mode;
     uint8_t* out_masks;      // null: coefficients go out as [block][64]; else they go out chunk-planar (as
                              // launch_fdct_quant describes it) and this receives [n][mcus*3] chunk masks
 };
@@ -174,7 +187,8 @@ void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t*
 
 // d_chunk_masks null: d_coefs is [image][mcu][channel][64]; else chunk-planar with these masks.
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
-                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks = nullptr);
+                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks = nullptr,
+                         ComponentMode mode = ComponentMode{});
 
 // Per-block (component granularity) launchers, blocks.hip.
 void launch_dct_forward_blocks(hipStream_t s, const uint8_t* d_in, size_t n, float* d_out);

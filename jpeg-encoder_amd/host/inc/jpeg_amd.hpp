@@ -104,7 +104,7 @@ public:
     void removeStuffedBytes(BitStreamReadProgress const& progress);
     /* Additions of this build. */
     void appendBytes(uint8_t const* data, size_t len);  // byte-aligned streams only
-    uint64_t revision() const { return m_revision; }     // changes whenever the contents change
+    uint64_t revision() const { return m_revision; }     // process-unique; changes whenever the contents change
     size_t committedBytes() const { return m_stream.size(); }
 
 private:
@@ -190,7 +190,7 @@ private:
 /* What a component contributes to the fused GPU path.  `none` means the component
    has no device implementation: the encoder then refuses to run (there is no host
    fallback for image arithmetic in this build). */
-enum class DeviceColourMapping { none, rgbToYCbCr };
+enum class DeviceColourMapping { none, rgbToYCbCr, rgbPassThrough };
 enum class DeviceTransform { none, separatedFloat };
 enum class DeviceEntropyCoding { none, annexKHuffman };
 
@@ -221,9 +221,13 @@ protected:
     virtual bool componentIsLuminance(uint8_t component) const = 0;
 };
 
-/* Pass-through mapper (colour_mapping.cpp:16-42): pure data movement, kept on the
-   host; it has no device path, so an Encoder built with it reports an error. */
+/* Pass-through mapper (colour_mapping.cpp:16-42): components are R, G, B as they are and all
+   three use the luminance tables.  Per block it is pure data movement on the host; inside
+   Encoder::encode / decode the GPU library runs with its pass-through colour mode. */
 class RGBToRGBMapper : public ColourMapper {
+public:
+    DeviceColourMapping deviceCapability() const override { return DeviceColourMapping::rgbPassThrough; }
+
 protected:
     ColourMappedBlockData applyMapping(BlockGrid::Block const& inputBlock) const override;
     BlockGrid::Block reverseMapping(ColourMappedBlockData const& inputBlock) const override;

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <atomic>
 #include <mutex>
 #include <stdexcept>
 
@@ -139,11 +140,18 @@ void BitStreamReadProgress::advanceIntoAlignment() {
 
 BitStream::BitStream() { clearStream(); }
 
+// Revisions are unique across all streams of the process, so equal revisions mean equal contents
+// (copies keep the number of the stream they were copied from).
+static uint64_t nextStreamRevision() {
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
+
 void BitStream::clearStream() {
     m_buffer = 0;
     m_bitsInBuffer = 0;
     m_stream.clear();
-    ++m_revision;
+    m_revision = nextStreamRevision();
 }
 
 size_t BitStream::getSize() { return m_stream.size() + (m_bitsInBuffer > 0 ? 1 : 0); }
@@ -151,7 +159,7 @@ size_t BitStream::getSize() { return m_stream.size() + (m_bitsInBuffer > 0 ? 1 :
 // Appends the `n` low bits of `data`, most significant first; a byte moves to the
 // stream as soon as it is complete (semantics of bit_stream.cpp:44-67).
 void BitStream::pushBitsu8(uint8_t data, size_t n) {
-    ++m_revision;
+    m_revision = nextStreamRevision();
     for (size_t i = n; i-- > 0;) {
         m_buffer = static_cast<uint8_t>((m_buffer << 1) | ((data >> i) & 1u));
         if (++m_bitsInBuffer == 8) {
@@ -202,7 +210,7 @@ uint8_t const* BitStream::getDataPtr() const { return m_stream.data(); }
 // A zero byte after every committed 0xFF from `from` on (intended semantics of
 // bit_stream.cpp:127-134), built in one pass.
 void BitStream::stuffBytes(size_t from) {
-    ++m_revision;
+    m_revision = nextStreamRevision();
     std::vector<uint8_t> out;
     out.reserve(m_stream.size() + m_stream.size() / 64 + 16);
     out.insert(out.end(), m_stream.begin(), m_stream.begin() + static_cast<std::ptrdiff_t>(std::min(from, m_stream.size())));
@@ -216,7 +224,7 @@ void BitStream::stuffBytes(size_t from) {
 // Drops the zero byte after each 0xFF between the read position and the final two
 // bytes (bit_stream.cpp:136-147).
 void BitStream::removeStuffedBytes(BitStreamReadProgress const& progress) {
-    ++m_revision;
+    m_revision = nextStreamRevision();
     if (m_stream.size() < progress.currentByte + 2) return;
     const size_t end = m_stream.size() - 2;
     size_t w = progress.currentByte;
@@ -235,7 +243,7 @@ void BitStream::removeStuffedBytes(BitStreamReadProgress const& progress) {
 
 void BitStream::appendBytes(uint8_t const* data, size_t len) {
     if (m_bitsInBuffer != 0) throw std::logic_error("BitStream::appendBytes on an unaligned stream");
-    ++m_revision;
+    m_revision = nextStreamRevision();
     m_stream.insert(m_stream.end(), data, data + len);
 }
 
@@ -490,17 +498,17 @@ void HuffmanEncoder::encode(QuantisedBlockChannelData const& input, int16_t& las
 
 QuantisedBlockChannelData HuffmanEncoder::decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
                                                  int16_t& lastDCValue, bool isLuminanceComponent) const {
-    // the GPU keeps a copy of the stream; it is refreshed when the stream object or its contents change
-    static BitStream const* uploadedStream = nullptr;
+    // the GPU keeps a copy of the stream; it is refreshed when the contents differ from the uploaded ones
+    static bool uploaded = false;
     static uint64_t uploadedRevision = 0;
     int16_t zz[64];
     uint64_t endBit = 0;
     {
         std::lock_guard<std::mutex> lock(g_component_mutex);
         jea_ctx* ctx = componentContext();
-        if (uploadedStream != &inputStream || uploadedRevision != inputStream.revision()) {
+        if (!uploaded || uploadedRevision != inputStream.revision()) {
             check(ctx, jea_stream_upload(ctx, inputStream.getDataPtr(), inputStream.committedBytes()));
-            uploadedStream = &inputStream;
+            uploaded = true;
             uploadedRevision = inputStream.revision();
         }
         check(ctx, jea_huffman_decode_block(ctx, 8 * static_cast<uint64_t>(readProgress.currentByte) + readProgress.currentBit,
@@ -533,13 +541,17 @@ void Encoder::setDevice(int deviceId) {
 jea_ctx* Encoder::context() {
     if (!m_context && jea_create(m_device, &m_context) != JEA_OK)
         throw std::runtime_error(std::string("GPU context: ") + jea_last_error(nullptr));
+    // the library's colour mode follows the injected mapper
+    const bool passThrough = m_colourMapper && m_colourMapper->deviceCapability() == DeviceColourMapping::rgbPassThrough;
+    if (jea_set_colour_mapper(m_context, passThrough ? JEA_MAPPER_RGB : JEA_MAPPER_YCBCR) != JEA_OK)
+        throw std::runtime_error(std::string("GPU context: ") + jea_last_error(m_context));
     return m_context;
 }
 
 void Encoder::requireDevicePath() const {
     if (!m_colourMapper || !m_discreteCosineTransformer || !m_quantiser || !m_entropyEncoder)
         throw std::runtime_error("Encoder is missing a component");
-    if (m_colourMapper->deviceCapability() != DeviceColourMapping::rgbToYCbCr)
+    if (m_colourMapper->deviceCapability() == DeviceColourMapping::none)
         throw std::runtime_error("The injected colour mapper has no GPU implementation");
     if (m_discreteCosineTransformer->deviceCapability() != DeviceTransform::separatedFloat)
         throw std::runtime_error("The injected cosine transformer has no GPU implementation");

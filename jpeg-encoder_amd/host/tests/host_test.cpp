@@ -40,8 +40,8 @@ static jpeg::BitmapImageRGB make_image(int w, int h, int mode, unsigned seed) {
 }
 
 // The reference's per-block encode loop, written against the component interfaces only.
-static void encode_block_by_block(jpeg::BitmapImageRGB const& bmp, int quality, jpeg::BitStream& out) {
-    jpeg::RGBToYCbCrMapper mapper;
+static void encode_block_by_block(jpeg::BitmapImageRGB const& bmp, int quality, jpeg::BitStream& out,
+                                  jpeg::ColourMapper const& mapper) {
     jpeg::SeparatedDiscreteCosineTransformer dct;
     jpeg::Quantiser quantiser(quality);
     jpeg::HuffmanEncoder huffman;
@@ -79,8 +79,7 @@ static void encode_block_by_block(jpeg::BitmapImageRGB const& bmp, int quality, 
 }
 
 // The reference's per-block decode loop (encoder.cpp:44-71) on the component interfaces.
-static jpeg::BitmapImageRGB decode_block_by_block(jpeg::JPEGImage jpg, int quality) {
-    jpeg::RGBToYCbCrMapper mapper;
+static jpeg::BitmapImageRGB decode_block_by_block(jpeg::JPEGImage jpg, int quality, jpeg::ColourMapper const& mapper) {
     jpeg::SeparatedDiscreteCosineTransformer dct;
     jpeg::Quantiser quantiser(quality);
     jpeg::HuffmanEncoder huffman;
@@ -103,6 +102,7 @@ static jpeg::BitmapImageRGB decode_block_by_block(jpeg::JPEGImage jpg, int quali
 }
 
 int main(int argc, char** argv) {
+    std::setvbuf(stdout, nullptr, _IOLBF, 0);  // lines survive an abort
     const uint64_t basis = 0x14650fb0739d0383ull;
     struct Case { int w, h, q, mode; };
     const Case cases[] = {{512, 512, 75, 0}, {512, 512, 75, 1}, {13, 7, 75, 1}, {17, 33, 90, 1}, {8, 8, 50, 0},
@@ -126,18 +126,18 @@ int main(int argc, char** argv) {
         jpeg::JPEGImage jpg;
         encoder.encode(bmp, jpg);
         jpeg::BitStream blockwise;
-        encode_block_by_block(bmp, 80, blockwise);
+        encode_block_by_block(bmp, 80, blockwise, jpeg::RGBToYCbCrMapper());
         const bool same = blockwise.getSize() == jpg.m_compressedImageData.getSize() &&
                           std::memcmp(blockwise.getDataPtr(), jpg.m_compressedImageData.getDataPtr(), blockwise.getSize()) == 0;
         std::printf("blockwise_encode_matches %d bytes %zu\n", int(same), blockwise.getSize());
         jpeg::BitmapImageRGB fused;
         encoder.decode(jpg, fused);
-        jpeg::BitmapImageRGB perBlock = decode_block_by_block(jpg, 80);
+        jpeg::BitmapImageRGB perBlock = decode_block_by_block(jpg, 80, jpeg::RGBToYCbCrMapper());
         const bool sameDec = fused.m_imageData.size() == perBlock.m_imageData.size() &&
                              std::memcmp(fused.m_imageData.data(), perBlock.m_imageData.data(), fused.m_imageData.size() * 3) == 0;
         std::printf("blockwise_decode_matches %d\n", int(sameDec));
     }
-    {   // an injected component without a GPU implementation: error printed, no throw, no output
+    {   // the other mapper the reference ships (colour_mapping.cpp:16-42), injected: fused path == per-block loop
         class PassThrough final : public jpeg::Encoder {
         public:
             PassThrough() : Encoder(std::make_unique<jpeg::RGBToRGBMapper>(), std::make_unique<jpeg::SeparatedDiscreteCosineTransformer>(),
@@ -145,9 +145,37 @@ int main(int argc, char** argv) {
         private:
             bool supportsSaving() const override { return false; }
         } passThrough;
-        jpeg::BitmapImageRGB bmp = make_image(16, 16, 0, 1);
+        jpeg::BitmapImageRGB bmp = make_image(40, 24, 1, 1);
         jpeg::JPEGImage jpg;
         passThrough.encode(bmp, jpg);
+        jpeg::BitStream blockwise;
+        encode_block_by_block(bmp, 50, blockwise, jpeg::RGBToRGBMapper());
+        const bool same = blockwise.getSize() == jpg.m_compressedImageData.getSize() &&
+                          std::memcmp(blockwise.getDataPtr(), jpg.m_compressedImageData.getDataPtr(), blockwise.getSize()) == 0;
+        std::printf("passthrough_encode_matches %d bytes %zu\n", int(same), blockwise.getSize());
+        jpeg::BitmapImageRGB fused;
+        passThrough.decode(jpg, fused);
+        jpeg::BitmapImageRGB perBlock = decode_block_by_block(jpg, 50, jpeg::RGBToRGBMapper());
+        const bool sameDec = fused.m_imageData.size() == perBlock.m_imageData.size() && !fused.m_imageData.empty() &&
+                             std::memcmp(fused.m_imageData.data(), perBlock.m_imageData.data(), fused.m_imageData.size() * 3) == 0;
+        std::printf("passthrough_decode_matches %d\n", int(sameDec));
+    }
+    {   // an injected component without a GPU implementation: error printed, no throw, no output
+        class HostOnlyTransform final : public jpeg::DiscreteCosineTransformer {
+        protected:
+            jpeg::DctBlockChannelData applyTransform(std::array<int8_t, jpeg::BlockGrid::blockElements> const&) const override { return {}; }
+            std::array<int8_t, jpeg::BlockGrid::blockElements> applyInverseTransform(jpeg::DctBlockChannelData const&) const override { return {}; }
+        };
+        class Custom final : public jpeg::Encoder {
+        public:
+            Custom() : Encoder(std::make_unique<jpeg::RGBToYCbCrMapper>(), std::make_unique<HostOnlyTransform>(),
+                               std::make_unique<jpeg::Quantiser>(50), std::make_unique<jpeg::HuffmanEncoder>()) {}
+        private:
+            bool supportsSaving() const override { return false; }
+        } custom;
+        jpeg::BitmapImageRGB bmp = make_image(16, 16, 0, 1);
+        jpeg::JPEGImage jpg;
+        custom.encode(bmp, jpg);
         std::printf("no_device_path_size %zu\n", jpg.m_compressedImageData.getSize());
     }
     {   // damaged header: the reference's message on stdout, output untouched

@@ -261,6 +261,15 @@ void jo_ycbcr_to_rgb_px(uint8_t Y, uint8_t Cb, uint8_t Cr, uint8_t out[3]) {
 }
 
 /* Bulk versions for exhaustive sweeps: n pixels, interleaved triples. */
+/* Colour mapper used by the whole-image functions below: 0 = RGBToYCbCrMapper
+ * (colour_mapping.cpp:44-97, what BaselineEncoder composes), 1 = RGBToRGBMapper
+ * (colour_mapping.cpp:16-42: components pass through, all three are "luminance").
+ * The reference hashes were recorded with mapper 0 only: mapper 1 is restated from
+ * the source and not pinned by any reference output. */
+static int jo_mapper = 0;
+void jo_set_mapper(int mapper) { jo_mapper = mapper ? 1 : 0; }
+static int jo_is_lum(int ch) { return jo_mapper ? 1 : ch == 0; }
+
 void jo_rgb_to_ycbcr(const uint8_t* rgb, size_t n, uint8_t* ycc) {
     for (size_t i = 0; i < n; ++i) jo_rgb_to_ycbcr_px(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], ycc + 3 * i);
 }
@@ -351,7 +360,8 @@ int jo_image_to_coefs(const uint8_t* rgb, int w, int h, const uint16_t lumq[64],
             uint8_t ycc[3][64];
             for (int i = 0; i < 64; ++i) {
                 uint8_t o[3];
-                jo_rgb_to_ycbcr_px(blk[i][0], blk[i][1], blk[i][2], o);
+                if (jo_mapper) { o[0] = blk[i][0]; o[1] = blk[i][1]; o[2] = blk[i][2]; }
+                else jo_rgb_to_ycbcr_px(blk[i][0], blk[i][1], blk[i][2], o);
                 ycc[0][i] = o[0]; ycc[1][i] = o[1]; ycc[2][i] = o[2];
             }
             for (int ch = 0; ch < 3; ++ch) {
@@ -360,7 +370,7 @@ int jo_image_to_coefs(const uint8_t* rgb, int w, int h, const uint16_t lumq[64],
                 int16_t q[64];
                 for (int i = 0; i < 64; ++i) shifted[i] = (int8_t)(ycc[ch][i] - 128);
                 jo_fdct(shifted, dct);
-                jo_quantise(dct, ch == 0 ? lumq : chrq, q);
+                jo_quantise(dct, jo_is_lum(ch) ? lumq : chrq, q);
                 int16_t* dst = coefs + ((size_t)(by * bw + bx) * 3 + ch) * 64;
                 for (int k = 0; k < 64; ++k) dst[k] = q[JO_ZIGZAG[k]];
             }
@@ -453,7 +463,7 @@ int jo_coefs_to_bit_lengths(const int16_t* coefs, size_t n_mcu, uint32_t* length
     int16_t last[3] = {0, 0, 0};
     for (size_t m = 0; m < n_mcu; ++m)
         for (int ch = 0; ch < 3; ++ch) {
-            int rc = jo_encode_block(coefs + (m * 3 + (size_t)ch) * 64, &last[ch], ch == 0, NULL,
+            int rc = jo_encode_block(coefs + (m * 3 + (size_t)ch) * 64, &last[ch], jo_is_lum(ch), NULL,
                                      &lengths[m * 3 + (size_t)ch]);
             if (rc) return rc;
         }
@@ -479,7 +489,7 @@ int jo_coefs_to_scan(const int16_t* coefs, size_t n_mcu, uint8_t* out, size_t ca
     for (size_t m = 0; m < n_mcu; ++m)
         for (int ch = 0; ch < 3; ++ch) {
             uint32_t nb = 0;
-            int rc = jo_encode_block(coefs + (m * 3 + (size_t)ch) * 64, &last[ch], ch == 0, &w, &nb);
+            int rc = jo_encode_block(coefs + (m * 3 + (size_t)ch) * 64, &last[ch], jo_is_lum(ch), &w, &nb);
             if (rc) { free(raw); return rc; }
             bits += nb;
         }
@@ -771,7 +781,7 @@ int jo_scan_to_coefs(const uint8_t* scan, size_t len, size_t n_mcu, int16_t* coe
     int16_t last[3] = {0, 0, 0};
     for (size_t m = 0; m < n_mcu; ++m)
         for (int ch = 0; ch < 3; ++ch) {
-            int rc = jo_decode_block(&r, ch == 0, &last[ch], coefs + (m * 3 + (size_t)ch) * 64);
+            int rc = jo_decode_block(&r, jo_is_lum(ch), &last[ch], coefs + (m * 3 + (size_t)ch) * 64);
             if (rc) return rc;
         }
     if (r.bit > 0) { r.bit = 0; r.byte++; }
@@ -795,7 +805,7 @@ int jo_coefs_to_image(const int16_t* coefs, int w, int h, const uint16_t lumq[64
                 float deq[64];
                 int8_t px[64];
                 for (int k = 0; k < 64; ++k) nat[JO_ZIGZAG[k]] = zz[k];
-                jo_dequantise(nat, ch == 0 ? lumq : chrq, deq);
+                jo_dequantise(nat, jo_is_lum(ch) ? lumq : chrq, deq);
                 jo_idct(deq, px);
                 for (int i = 0; i < 64; ++i) ycc[ch][i] = (uint8_t)(px[i] + 128);
             }
@@ -804,7 +814,9 @@ int jo_coefs_to_image(const int16_t* coefs, int w, int h, const uint16_t lumq[64
                 for (int col = 0; col < 8; ++col) {
                     int xx = bx * 8 + col; if (xx >= w) break;
                     int i = 8 * row + col;
-                    jo_ycbcr_to_rgb_px(ycc[0][i], ycc[1][i], ycc[2][i], rgb + 3 * ((size_t)yy * (size_t)w + (size_t)xx));
+                    uint8_t* px = rgb + 3 * ((size_t)yy * (size_t)w + (size_t)xx);
+                    if (jo_mapper) { px[0] = ycc[0][i]; px[1] = ycc[1][i]; px[2] = ycc[2][i]; }
+                    else jo_ycbcr_to_rgb_px(ycc[0][i], ycc[1][i], ycc[2][i], px);
                 }
             }
         }

@@ -37,6 +37,8 @@ def _load():
     lib.jo_encode.argtypes = [_vp, _int, _int, _int, _vp, _sz, _c.POINTER(_sz)]
     lib.jo_decode.argtypes = [_vp, _sz, _int, _int, _int, _vp]
     lib.jo_quant_tables.argtypes = [_int, _vp, _vp]
+    lib.jo_set_mapper.argtypes = [_int]
+    lib.jo_set_mapper.restype = None
     lib.jo_image_to_coefs.argtypes = [_vp, _int, _int, _vp, _vp, _vp]
     lib.jo_coefs_to_bit_lengths.argtypes = [_vp, _sz, _vp]
     lib.jo_coefs_to_scan.argtypes = [_vp, _sz, _vp, _sz, _c.POINTER(_sz), _c.POINTER(_c.c_uint64)]
@@ -100,6 +102,12 @@ def encode(rgb, quality):
     if rc:
         raise RuntimeError("jo_encode rc=%d" % rc)
     return out[: n.value].tobytes()
+
+
+def set_mapper(mapper):
+    """0: RGBToYCbCrMapper (default); 1: RGBToRGBMapper -- for the whole-image functions (encode, decode,
+    image_to_coefs, coefs_to_scan, scan_to_coefs, coefs_to_image).  Not pinned by reference outputs."""
+    LIB.jo_set_mapper(int(mapper))
 
 
 def decode(jpeg, w, h, quality):

@@ -370,6 +370,32 @@ def test_decode_with_the_files_own_header(ctx, po, jea):
         assert np.array_equal(ctx.decode_host(jpeg, rw, rh, lum, chrom), po.decode(jpeg, w, h, quality))
 
 
+def test_rgb_passthrough_mapper(po, jea):
+    """RGBToRGBMapper (colour_mapping.cpp:16-42) on the device: components pass through and all use the
+    luminance tables.  The oracle's restatement of this mapper is not pinned by reference outputs."""
+    ctx = jea.Context(0)
+    try:
+        ctx.set_colour_mapper(1)
+        po.set_mapper(1)
+        for (w, h, quality, mode) in [(64, 48, 75, 1), (200, 120, 50, 0), (13, 7, 90, 1), (520, 333, 75, 1)]:
+            lum, chrom = jea.binding.quant_tables(quality)
+            rgb = po.gen_image(w, h, mode, 5)
+            coefs = po.image_to_coefs(rgb, lum, chrom)
+            got = ctx.fdct_quant(ctx.to_device(rgb.reshape(-1)), 1, w, h, lum, chrom).cpu().numpy().reshape(-1, 3, 64)
+            assert np.array_equal(got, coefs), (w, h, "coefficients")
+            want = po.encode(rgb, quality)
+            jpeg = ctx.encode_host(rgb, lum, chrom)
+            assert jpeg == want, (w, h, "file")
+            assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(want, w, h, quality)), (w, h, "decode")
+        # the mappers give different files, and the default one is back after the switch
+        po.set_mapper(0)
+        ctx.set_colour_mapper(0)
+        assert ctx.encode_host(rgb, lum, chrom) == po.encode(rgb, quality) != want
+    finally:
+        po.set_mapper(0)
+        ctx.close()
+
+
 def test_decode_errors(ctx, po, jea):
     """Error surface of encoder.cpp:63-65,140-283 and entropy_encoder.cpp:776."""
     w, h, quality = 32, 32, 75

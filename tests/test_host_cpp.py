@@ -43,7 +43,10 @@ def test_baseline_encoder_cpp_on_gpu(tmp_path):
     assert "blockwise_decode_matches 1" in lines
     assert "blockwise_decode_eoi_missing" not in r.stdout
     # injected component without a GPU implementation: reference error convention, nothing produced
-    assert "[Error]: The injected colour mapper has no GPU implementation" in lines
+    # the reference's other mapper, injected: the GPU path equals the per-block loop
+    assert any(ln.startswith("passthrough_encode_matches 1") for ln in lines), r.stdout
+    assert "passthrough_decode_matches 1" in lines
+    assert "[Error]: The injected cosine transformer has no GPU implementation" in lines
     assert "no_device_path_size 0" in lines
     assert "[Error]: Failed to find SOI marker" in lines
     assert "broken_header_pixels 0" in lines
