@@ -115,27 +115,32 @@ __device__ __forceinline__ int quantise_exact(float o, float q) {
 // another 2^-24), so floor(t + 0.5) is the reference's result unless t lies
 // within that distance of a half-integer; such lanes are flagged and redone
 // with quantise_exact.  v_cvt_rpi_i32_f32 is floor(x + 0.5) as an integer; its
-// own rounding of x + 0.5 is covered by the same margin.
-__device__ __forceinline__ int quantise_fast(float o, float rq, bool& ambiguous) {
+// own rounding of x + 0.5 is covered by the same margin.  The test runs once per column of eight.
+// Returns the rounded value; `margin` receives (distance of t to the nearest half-integer) minus
+// |t| * 2^-20: the value is settled when margin >= 2^-22.
+__device__ __forceinline__ int quantise_fast(float o, float rq, float& margin) {
     const float t = o * rq;
     int n;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(n) : "v"(t));
-    const float e = __builtin_fabsf(__builtin_amdgcn_fractf(t) - 0.5f);
-    ambiguous = e < __builtin_fabsf(t) * 0x1p-20f + 0x1p-22f;
+    const float s = __builtin_amdgcn_fractf(t) - 0.5f;
+    margin = __builtin_fmaf(-__builtin_fabsf(t), 0x1p-20f, __builtin_fabsf(s));
     return n;
+}
+
+__device__ __forceinline__ float min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 // Quantises the eight coefficients out[8v+u], v = 0..7, of one column u.
 __device__ __forceinline__ void quantise_col(const float (&o)[8], const float* __restrict__ qt,
                                              const float* __restrict__ rqt, int u, int* __restrict__ qv) {
-    bool any = false;
+    float m[8];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        bool amb;
-        qv[8 * v + u] = quantise_fast(o[v], rqt[8 * u + v], amb);  // tables are stored [u][v]
-        any |= amb;
-    }
-    if (__builtin_expect(any, 0)) {
+    for (int v = 0; v < 8; ++v) qv[8 * v + u] = quantise_fast(o[v], rqt[8 * u + v], m[v]);  // tables are stored [u][v]
+    const float worst = min3(min3(m[0], m[1], m[2]), min3(m[3], m[4], m[5]), min3(m[6], m[7], m[7]));
+    if (__builtin_expect(worst < 0x1p-22f, 0)) {
 #pragma unroll
         for (int v = 0; v < 8; ++v) qv[8 * v + u] = quantise_exact(o[v], qt[8 * u + v]);
     }
