@@ -39,23 +39,28 @@ __device__ __forceinline__ void colour_constants(int channel, double& k, double&
 // M = 1000 for Y and M = 31250 for Cb, Cr (0.168736 = 5273/31250, 0.331264 = 10352/31250,
 // 0.5 = 15625/31250, 0.418688 = 13084/31250, 0.081312 = 2541/31250), so that
 //   value = t / M,   t = k + a r + b g + c b   an integer below 2^24 in magnitude,
-// and floor(value + 0.5) - 128 = floor((t + M/2 - 128 M) / M).  The numerator is formed with
-// three FMAs that are exact (every intermediate is an integer below 2^24), the division is a
-// multiply by RN(1/M): q is within 128 * 2^-23 < 3.1e-5 of the true quotient, whose distance to
-// the next integer is either 0 (value + 0.5 is an integer: a rounding tie, where the reference's
-// double arithmetic decides and only the literal double formula can tell which way) or at least
-// 1/M = 3.2e-5.  Quotients closer than 1e-4 to an integer are therefore flagged and redone with
-// colour_forward; for all others floor(q) is the reference's result, and it needs no clamp
-// because an unflagged value + 0.5 lies strictly inside (0, 256).
+// and floor(value + 0.5) - 128 = floor((t + M/2 - 128 M) / M).  A rounding tie of the reference
+// (value + 0.5 an integer, where its double arithmetic decides and only the literal double
+// formula can tell which way) is a numerator that is a multiple of M; every other numerator is at
+// least 1/M = 3.2e-5 away from an integer quotient.
+//
+// The numerator is formed with three FMAs that are exact, with d*M added on top (d = 1.25e-4 for
+// Y: 0.125, d = 1.28e-4 for Cb, Cr: 4; both keep every intermediate exactly representable), and
+// divided by a multiply with RN(1/M): q is within 128 * 2^-23 < 3.1e-5 of (t / M) + d.  So
+//   fract(q) <  2d : t / M is within d + 3.1e-5 of an integer (every tie is: its fract(q) lies in
+//                    [d - 3.1e-5, d + 3.1e-5]) -> flagged, redone with colour_forward
+//   fract(q) >= 2d : t / M has a fractional part in (d - 3.1e-5, 1 - d + 3.1e-5), hence
+//                    floor(q) = floor(t / M), the reference's result; it needs no clamp because
+//                    an unflagged value + 0.5 lies strictly inside (0, 256).
 struct ColourInt {
-    float k, a, b, c, rcp_m;
+    float k, a, b, c, rcp_m, window;
 };
 __device__ __forceinline__ ColourInt colour_int_constants(int channel) {
     ColourInt ci;
-    // k = (constant term) * M + M/2 - 128 M; for the chroma channels 128 M - 128 M cancels
-    if (channel == 0) ci = ColourInt{500.0f - 128000.0f, 299.0f, 587.0f, 114.0f, 1.0f / 1000.0f};
-    else if (channel == 1) ci = ColourInt{15625.0f, -5273.0f, -10352.0f, 15625.0f, 1.0f / 31250.0f};
-    else ci = ColourInt{15625.0f, 15625.0f, -13084.0f, -2541.0f, 1.0f / 31250.0f};
+    // k = (constant term) * M + M/2 - 128 M + d M; for the chroma channels 128 M - 128 M cancels
+    if (channel == 0) ci = ColourInt{500.0f - 128000.0f + 0.125f, 299.0f, 587.0f, 114.0f, 1.0f / 1000.0f, 2.5e-4f};
+    else if (channel == 1) ci = ColourInt{15625.0f + 4.0f, -5273.0f, -10352.0f, 15625.0f, 1.0f / 31250.0f, 2.56e-4f};
+    else ci = ColourInt{15625.0f + 4.0f, 15625.0f, -13084.0f, -2541.0f, 1.0f / 31250.0f, 2.56e-4f};
     return ci;
 }
 // Level-shifted sample (value rounded, minus 128) as a float; `tie` is set when it must be redone.
@@ -63,7 +68,7 @@ __device__ __forceinline__ float colour_forward_shifted_fast(const ColourInt& ci
     const float t = __builtin_fmaf(ci.c, b, __builtin_fmaf(ci.b, g, __builtin_fmaf(ci.a, r, ci.k)));
     const float q = t * ci.rcp_m;
     const float fr = __builtin_amdgcn_fractf(q);      // q - floor(q), exact
-    tie = __builtin_fabsf(fr - 0.5f) > 0.4999f;
+    tie = fr < ci.window;
     return q - fr;
 }
 
