@@ -104,7 +104,10 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
     if (active) {
         double ck, ca, cb, cc;
         colour_constants(channel, ck, ca, cb, cc);
-        const ColourInt ci = colour_int_constants(channel);
+        ColourInt ci = colour_int_constants(channel);
+        // the constant term lives in a vector register: as a scalar it would be copied there again for
+        // every pixel (an fma takes one scalar operand, and the coefficient is the other)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci.k) : "s"(ci.k));
         if (mode.passthrough) {
             // RGBToRGBMapper (colour_mapping.cpp:16-26): the component as it is.  A loop of its own,
             // so that the usual path carries no test per pixel.
