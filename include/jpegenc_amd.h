@@ -162,7 +162,9 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
  * bytes.  As in the reference, the output dimensions are the caller's
  * (JPEGImage::m_width/m_height, encoder.cpp:46), not the SOF0 fields, and the
  * tables are the caller's, not the file's DQT (encoder.cpp:187-188).  Image i is
- * written to d_rgb + i*3*width*height. */
+ * written to d_rgb + i*3*width*height.  When an error is returned the contents
+ * of d_rgb are unspecified (jea_decode_host and the C++ Encoder::decode leave
+ * the caller's output untouched in that case, as encoder.cpp:63-70 does). */
 int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offsets, const uint64_t* h_sizes,
                      size_t n_images, uint16_t width, uint16_t height, const uint16_t lum_q[64],
                      const uint16_t chr_q[64], uint8_t* d_rgb);

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,8 @@ struct jea_ctx {
     // parallel decode
     DeviceBuffer seg_ubase, ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
         round_flags, grp_pending, sub_guess, first_bad, ctx_keys, ctx_vals;
+    void* pinned = nullptr;   // host memory the GPU reads and writes: decode bookkeeping
+    size_t pinned_bytes = 0;
     size_t stream_len = 0;
     // stripe encode in progress (jea_stripe_*)
     size_t stripe_mcus = 0;
@@ -78,6 +81,18 @@ int ensure(jea_ctx* ctx, DeviceBuffer& b, size_t bytes) {
     const size_t want = bytes + bytes / 8 + 256;
     JEA_HIP(ctx, hipMalloc(&b.ptr, want));
     b.bytes = want;
+    return JEA_OK;
+}
+
+int ensure_pinned(jea_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes) return JEA_OK;
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pinned) JEA_HIP(ctx, hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    JEA_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
     return JEA_OK;
 }
 
@@ -291,6 +306,7 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->round_flags, &ctx->grp_pending, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
                             &ctx->ctx_vals})
         free_buffer(*b);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_decode) (void)hipFree(ctx->d_decode);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
@@ -753,12 +769,22 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
 
 // ---- decode -------------------------------------------------------------------
 
-// Uploads the scan ranges (file ranges minus `skip` leading header bytes), sizes the
-// scratch of the parallel decoder, runs it and reports the device status under the name `what`.
+// Uploads the scan ranges (file ranges minus `skip` leading header bytes), sizes the scratch of the
+// parallel decoder, enqueues it followed by `follow_up` (the consumer of the coefficients, if any),
+// waits once and reports headers and device status under the name `what`.  Headers travel to the
+// host while the decoder runs and are judged first, as the reference does (encoder.cpp:48); what the
+// kernels made of a file with a bad header is bounded and thrown away.
 static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_t* h_offsets, const uint64_t* h_sizes,
                               size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs, const char* what,
-                              uint8_t* d_planar_masks = nullptr) {
-    std::vector<uint64_t> seg(3 * n_images);   // offsets | sizes | unstuffed bases
+                              uint8_t* d_planar_masks = nullptr, const std::function<void()>& follow_up = nullptr) {
+    int rc;
+    const bool with_headers = skip == JEA_HEADER_BYTES;
+    const size_t seg_bytes = 3 * n_images * sizeof(uint64_t);   // offsets | sizes | unstuffed bases
+    const size_t hdr_bytes = with_headers ? n_images * JEA_HEADER_BYTES : 0;
+    if ((rc = ensure_pinned(ctx, 64 + seg_bytes + hdr_bytes))) return rc;
+    DecodeReport* report = (DecodeReport*)ctx->pinned;
+    uint64_t* seg = (uint64_t*)((uint8_t*)ctx->pinned + 64);
+    uint8_t* hdr = (uint8_t*)ctx->pinned + 64 + seg_bytes;
     uint64_t max_size = 0, ubytes = 0;
     bool too_short = false;   // reported after the headers have been looked at, as the reference would
     for (size_t i = 0; i < n_images; ++i) {
@@ -774,8 +800,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
         return fail(ctx, JEA_ERR_INVALID_ARG, "decode: image or stream too large");
     const DecodePlan plan = plan_entropy_decode(n_images, max_size, mcus);
     const size_t subs = plan.subs_per_image;
-    int rc;
-    if ((rc = ensure(ctx, ctx->seg_offsets, 3 * n_images * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->seg_offsets, seg_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->ustream, ubytes))) return rc;
     if ((rc = ensure(ctx, ctx->chunk_drops, n_images * plan.n_chunks * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->chunk_base, n_images * plan.n_chunks * sizeof(uint64_t)))) return rc;
@@ -792,26 +817,29 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     if ((rc = ensure(ctx, ctx->first_bad, n_images * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ctx_keys, kContextSlots * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->ctx_vals, kContextSlots * sizeof(uint32_t)))) return rc;
-    // the vector dies at return: use the blocking copy
-    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    JEA_HIP(ctx, hipMemcpy(ctx->seg_offsets.ptr, seg.data(), seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (with_headers && (rc = ensure(ctx, ctx->small, hdr_bytes))) return rc;
+    // the pinned block is this context's and the call ends with a wait: the copies may run behind the host
+    JEA_HIP(ctx, hipMemcpyAsync(ctx->seg_offsets.ptr, seg, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
     const uint64_t* d_seg = (const uint64_t*)ctx->seg_offsets.ptr;
-    if (skip == JEA_HEADER_BYTES) {
-        // Header validation on the host, as the reference does before touching scan data (encoder.cpp:48);
-        // one gather and one transfer for the whole batch.
-        if ((rc = ensure(ctx, ctx->small, n_images * JEA_HEADER_BYTES))) return rc;
-        std::vector<uint8_t> hdr(n_images * JEA_HEADER_BYTES);
-        launch_gather_headers(ctx->stream, d_data, d_seg, n_images, JEA_HEADER_BYTES, (uint8_t*)ctx->small.ptr);
-        JEA_HIP(ctx, hipGetLastError());
-        JEA_HIP(ctx, hipMemcpyAsync(hdr.data(), ctx->small.ptr, hdr.size(), hipMemcpyDeviceToHost, ctx->stream));
-        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto headers_ok = [&]() -> int {
         for (size_t i = 0; i < n_images; ++i) {
             const char* msg = nullptr;
-            if (jea_check_header(hdr.data() + i * JEA_HEADER_BYTES, JEA_HEADER_BYTES, nullptr, nullptr, &msg) != JEA_OK)
+            if (jea_check_header(hdr + i * JEA_HEADER_BYTES, JEA_HEADER_BYTES, nullptr, nullptr, &msg) != JEA_OK)
                 return fail(ctx, JEA_ERR_BAD_HEADER, msg);
         }
+        return JEA_OK;
+    };
+    if (with_headers) {
+        // one gather and one transfer for the whole batch
+        launch_gather_headers(ctx->stream, d_data, d_seg, n_images, JEA_HEADER_BYTES, (uint8_t*)ctx->small.ptr);
+        JEA_HIP(ctx, hipGetLastError());
+        JEA_HIP(ctx, hipMemcpyAsync(hdr, ctx->small.ptr, hdr_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (too_short) return fail(ctx, JEA_ERR_NO_EOI, "Failed to find EOI marker");
+    if (too_short) {   // nothing to decode: only the order of the two messages matters
+        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (with_headers && (rc = headers_ok())) return rc;
+        return fail(ctx, JEA_ERR_NO_EOI, "Failed to find EOI marker");
+    }
     DecodeScratch sc;
     sc.ubase = d_seg + 2 * n_images;
     sc.ustream = (uint8_t*)ctx->ustream.ptr;
@@ -833,10 +861,14 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.ctx_vals = (uint32_t*)ctx->ctx_vals.ptr;
     sc.ctx_slots = kContextSlots;
     JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
-    int32_t st = 0;
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs,
-                                       ctx->d_status, &st));
-    return report_status(ctx, st, what);
+                                       ctx->d_status, follow_up, report));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (with_headers && (rc = headers_ok())) return rc;
+    if (report->unsettled != 0)
+        JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs, ctx->d_status,
+                                           follow_up, report));
+    return report_status(ctx, report->status, what);
 }
 
 int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_offsets, const uint64_t* h_sizes,
@@ -865,14 +897,15 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
     // the coefficients stay inside the library: chunk-planar layout with chunk masks
     if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3))) return rc;
-    if ((rc = run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,
-                                 (int16_t*)ctx->coefs.ptr, "jea_decode_batch", (uint8_t*)ctx->masks.ptr)))
-        return rc;   // as in the reference, nothing is written to the output when the stream is bad (encoder.cpp:63-70)
-    launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height,
-                        to_float_tables(lum_q, chr_q), d_rgb, (const uint8_t*)ctx->masks.ptr, ctx->mode);
-    JEA_HIP(ctx, hipGetLastError());
-    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return JEA_OK;
+    // The inverse transform is enqueued right behind the write pass, before anything is known about the
+    // stream: a decode waits for the GPU once.  So when an error is reported, d_rgb holds garbage.
+    const QuantTables qt = to_float_tables(lum_q, chr_q);
+    auto inverse = [&]() {
+        launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height, qt, d_rgb,
+                            (const uint8_t*)ctx->masks.ptr, ctx->mode);
+    };
+    return run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,
+                              (int16_t*)ctx->coefs.ptr, "jea_decode_batch", (uint8_t*)ctx->masks.ptr, inverse);
 }
 
 int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t width, uint16_t height,

@@ -839,83 +839,101 @@ DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mc
 }
 
 namespace {
+__global__ void report_kernel(const uint32_t* __restrict__ unsettled, const int32_t* __restrict__ status,
+                              DecodeReport* __restrict__ report) {
+    report->unsettled = *unsettled;
+    report->status = *status;
+}
+
 template <uint32_t W>
-hipError_t run_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
-                      const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status, int32_t* h_status) {
-    hipError_t e;
-    const dim3 ggrid(p.n_groups, p.n_images);
-    auto sync_round = [&](int first, uint32_t* flag, bool with_guesses) {
-        decode_sync_kernel<W><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
+struct DecodeRun {
+    hipStream_t s;
+    const uint64_t* d_sizes;
+    const DecodePlan& p;
+    const DecodeScratch& sc;
+    const DecodeTables* d_tables;
+    int16_t* d_coefs;
+    int32_t* d_status;
+
+    dim3 grid() const { return dim3(p.n_groups, p.n_images); }
+    void sync_round(int first, uint32_t* flag, bool with_guesses) const {
+        decode_sync_kernel<W><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
                                                          d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
                                                          sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
                                                          sc.first_bad, sc.mode.lum_mask, flag);
-    };
-    auto scan_and_write = [&]() {
+    }
+    void scan_and_write() const {
         scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
                                                            d_status);
         if (sc.out_masks != nullptr)
-            decode_write_kernel<W, true><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
+            decode_write_kernel<W, true><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
                                                                     p.n_groups, p.total_blocks, d_tables, sc.sub_used,
                                                                     sc.sub_info, sc.grp_base, d_coefs, sc.out_masks,
                                                                     sc.mode.lum_mask, d_status);
         else
-            decode_write_kernel<W, false><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
+            decode_write_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
                                                                      p.n_groups, p.total_blocks, d_tables, sc.sub_used,
                                                                      sc.sub_info, sc.grp_base, d_coefs, nullptr,
                                                                      sc.mode.lum_mask, d_status);
-    };
+    }
+
     // Three rounds up front: the first decodes everything, the second repairs the starts of the
     // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.
-    // The write pass follows at once; whether the third round was indeed idle is read back together
-    // with the status, so the usual decode waits for the GPU only once.
-    sync_round(1, sc.changed + 0, false);
-    sync_round(0, sc.changed + 1, false);
-    sync_round(0, sc.changed + 2, false);
-    scan_and_write();
-    uint32_t changed = 0;
-    if ((e = hipMemcpyAsync(&changed, sc.changed + 2, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(h_status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    if (changed == 0) return hipGetLastError();
+    // The write pass and whatever consumes the coefficients follow at once; whether the third round was
+    // indeed idle is reported together with the status, so the usual decode never waits for the GPU
+    // in the middle.
+    hipError_t first_pass(const std::function<void()>& follow_up, DecodeReport* report) const {
+        sync_round(1, sc.changed + 0, false);
+        sync_round(0, sc.changed + 1, false);
+        sync_round(0, sc.changed + 2, false);
+        scan_and_write();
+        if (follow_up) follow_up();
+        report_kernel<<<1, 1, 0, s>>>(sc.changed + 2, d_status, report);
+        return hipGetLastError();
+    }
+
     // The stream does not re-synchronise somewhere.  More rounds follow, each of which extends the
     // proven head of the stream by at least kMaxLocalIterations sub-sequences; in the first few, the
     // proven start states are offered as guesses wherever the same 512 stream bits come before
     // (periodic streams of flat or patterned pictures then settle in a handful of rounds).  What the
     // write pass produced from the unfinished states (bounded, but meaningless) is produced again.
-    const uint64_t max_rounds = (uint64_t)p.subs_per_image / kMaxLocalIterations + p.n_groups + 8;
-    if ((e = hipMemsetAsync(sc.ctx_keys, 0, (size_t)sc.ctx_slots * sizeof(unsigned long long), s)) != hipSuccess) return e;
-    for (uint64_t extra = 0; changed != 0; ++extra) {
-        if (extra > max_rounds) return hipErrorUnknown;
-        const bool guesses = extra < 64;
-        if (guesses) {
-            if ((e = hipMemsetAsync(sc.first_bad, 0xff, p.n_images * sizeof(uint32_t), s)) != hipSuccess) return e;
-            first_unproven_kernel<W><<<ggrid, kThreads, 0, s>>>(d_sizes, sc.img_drops, p.n_groups, sc.sub_end,
-                                                                sc.sub_used, sc.first_bad);
-            context_kernel<W, true><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
-                                                               sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
-                                                               sc.ctx_slots - 1, sc.sub_guess);
-            context_kernel<W, false><<<ggrid, kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
-                                                                sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
-                                                                sc.ctx_slots - 1, sc.sub_guess);
+    hipError_t repair(const std::function<void()>& follow_up, DecodeReport* report) const {
+        hipError_t e;
+        const uint64_t max_rounds = (uint64_t)p.subs_per_image / kMaxLocalIterations + p.n_groups + 8;
+        if ((e = hipMemsetAsync(sc.ctx_keys, 0, (size_t)sc.ctx_slots * sizeof(unsigned long long), s)) != hipSuccess) return e;
+        for (uint64_t extra = 0; report->unsettled != 0; ++extra) {
+            if (extra > max_rounds) return hipErrorUnknown;
+            const bool guesses = extra < 64;
+            if (guesses) {
+                if ((e = hipMemsetAsync(sc.first_bad, 0xff, p.n_images * sizeof(uint32_t), s)) != hipSuccess) return e;
+                first_unproven_kernel<W><<<grid(), kThreads, 0, s>>>(d_sizes, sc.img_drops, p.n_groups, sc.sub_end,
+                                                                    sc.sub_used, sc.first_bad);
+                context_kernel<W, true><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                                   sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
+                                                                   sc.ctx_slots - 1, sc.sub_guess);
+                context_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                                                                    sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
+                                                                    sc.ctx_slots - 1, sc.sub_guess);
+            }
+            if ((e = hipMemsetAsync(sc.changed + 3, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
+            sync_round(0, sc.changed + 3, guesses);
+            report_kernel<<<1, 1, 0, s>>>(sc.changed + 3, d_status, report);
+            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         }
-        if ((e = hipMemsetAsync(sc.changed + 3, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
-        sync_round(0, sc.changed + 3, guesses);
-        if ((e = hipMemcpyAsync(&changed, sc.changed + 3, sizeof(changed), hipMemcpyDeviceToHost, s)) != hipSuccess)
-            return e;
+        if ((e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s)) != hipSuccess) return e;
+        scan_and_write();
+        if (follow_up) follow_up();
+        report_kernel<<<1, 1, 0, s>>>(sc.changed + 3, d_status, report);
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        return hipGetLastError();
     }
-    if ((e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s)) != hipSuccess) return e;
-    scan_and_write();
-    if ((e = hipMemcpyAsync(h_status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    return hipGetLastError();
-}
+};
 }  // namespace
 
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
                                  const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
-                                 int32_t* h_status) {
+                                 const std::function<void()>& follow_up, DecodeReport* report) {
     hipError_t e;
     const dim3 cgrid(p.n_chunks, p.n_images);
     unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops);
@@ -924,9 +942,25 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
                                                       sc.ustream);
     if ((e = hipMemsetAsync(sc.changed, 0, 4 * sizeof(uint32_t), s)) != hipSuccess) return e;
     switch (p.sub_words) {
-        case kSubWordsSmall: return run_decode<kSubWordsSmall>(s, d_sizes, p, sc, d_tables, d_coefs, d_status, h_status);
-        case kSubWordsMedium: return run_decode<kSubWordsMedium>(s, d_sizes, p, sc, d_tables, d_coefs, d_status, h_status);
-        default: return run_decode<kSubWordsLarge>(s, d_sizes, p, sc, d_tables, d_coefs, d_status, h_status);
+        case kSubWordsSmall:
+            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);
+        case kSubWordsMedium:
+            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);
+        default:
+            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);
+    }
+}
+
+hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
+                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const std::function<void()>& follow_up, DecodeReport* report) {
+    switch (p.sub_words) {
+        case kSubWordsSmall:
+            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.repair(follow_up, report);
+        case kSubWordsMedium:
+            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.repair(follow_up, report);
+        default:
+            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.repair(follow_up, report);
     }
 }
 

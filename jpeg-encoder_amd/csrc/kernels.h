@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
+
 #include <cstddef>
 #include <cstdint>
 
@@ -172,13 +174,28 @@ struct DecodeScratch {
                              // launch_fdct_quant describes it) and this receives [n][mcus*3] chunk masks
 };
 
-// Enqueues the whole decode and, unlike the other launchers, waits on the stream
-// at the end (it has to read back whether the last synchronisation round changed
-// anything; if so more rounds follow) -- *h_status receives *d_status on that occasion.  Every block of d_coefs is written (chunk-planar: chunk 0 and the non-zero chunks);
-// errors go to *d_status.
+// What the decoder tells the host, in host memory that the GPU can write (hipHostMalloc).
+struct DecodeReport {
+    uint32_t unsettled;   // the last of the standard synchronisation rounds still changed something
+    int32_t status;       // *d_status after the write pass
+};
+
+// Enqueues the whole decode -- unstuffing, three synchronisation rounds, scan and write pass -- then
+// `follow_up` (work that consumes the coefficients; may be empty), then a copy of the outcome to
+// *report, and returns without waiting.  Every block of d_coefs is written (chunk-planar: chunk 0 and
+// the non-zero chunks); errors go to *d_status.  After the stream has been waited on:
+// report->unsettled == 0 is the usual case and the coefficients are final; otherwise
+// repair_entropy_decode has to run.
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
-                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status, int32_t* h_status);
+                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const std::function<void()>& follow_up, DecodeReport* report);
+
+// For streams that the standard rounds did not settle: more rounds (waiting on the stream after each),
+// then the write pass, `follow_up` and the report again, and a final wait.
+hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
+                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const std::function<void()>& follow_up, DecodeReport* report);
 
 // Copies the header_bytes bytes in front of each scan (d_scan_offsets[i] is the scan's offset in
 // d_data) to d_out back to back, so that the host can validate all headers with one transfer.
