@@ -38,6 +38,7 @@ struct jea_ctx {
     std::string error;
     HuffTables* d_huff = nullptr;
     DecodeTables* d_decode = nullptr;
+    StepTables* d_steps = nullptr;
     int32_t* d_status = nullptr;
     ComponentMode mode;   // jea_set_colour_mapper
     // scratch, grown on demand and kept
@@ -135,6 +136,48 @@ bool build_decode_table(const uint8_t bits[16], const uint8_t* vals, DecodeTable
         }
         code <<= 1;
     }
+    return true;
+}
+
+// The parallel decoder's view of the same code (kernels.h, StepTable).
+bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, StepTable& t) {
+    const uint32_t bad = kStepBad | (0u << 16) | (0u << 8) | 1u;   // skip one bit, keep going
+    for (uint32_t& e : t.fast) e = bad;
+    for (uint32_t& e : t.slow) e = bad;
+    t.first_long = 65536;
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    uint32_t code = 0;
+    int k = 0;
+    for (uint32_t l = 1; l <= 16; ++l) {
+        for (int i = 0; i < bits[l - 1]; ++i, ++k) {
+            const uint32_t sym = vals[k];
+            const uint32_t ss = is_dc ? sym : (sym & 15u), run = is_dc ? 0u : (sym >> 4);
+            // entropy_encoder.cpp:786-806, 830-864: sizes above 11 (DC) / 10 (AC) and AC symbols
+            // without amplitude other than EOB and ZRL do not exist
+            const bool valid = is_dc ? sym <= 11u : (ss <= 10u && (ss != 0u || sym == 0x00u || sym == 0xF0u));
+            uint32_t entry = bad;
+            if (valid) {
+                const uint32_t run_code = (!is_dc && sym == 0x00u) ? kStepRunEob : run;
+                entry = (l + ss) | (run_code << 8) | (l << 16) | (((32u - ss) & 31u) << 24);
+                if (ss) entry |= kStepHasAmp | (is_dc ? kStepDcAdd : 0u);
+            }
+            if (l <= 9) {
+                const uint32_t first = code << (9 - l);
+                for (uint32_t j = 0; j < (1u << (9 - l)); ++j) t.fast[first + j] = entry;
+            } else {
+                const uint32_t first = code << (16 - l);
+                if (t.first_long == 65536) t.first_long = first;
+                if (first + (1u << (16 - l)) - t.first_long > (uint32_t)kDecodeSlowEntries) return false;
+                for (uint32_t j = 0; j < (1u << (16 - l)); ++j) t.slow[first + j - t.first_long] = entry;
+            }
+            ++code;
+        }
+        code <<= 1;
+    }
+    // every prefix from the first long code word on is resolved through slow[] (0 = "look there"),
+    // the ones above the last code word included
+    if (t.first_long != 65536)
+        for (uint32_t j = t.first_long >> 7; j < 512; ++j) t.fast[j] = 0;
     return true;
 }
 
@@ -284,6 +327,14 @@ int jea_create(int device_id, jea_ctx** out_ctx) {
         jea_destroy(ctx);
         return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: Huffman tables do not fit the decode tables");
     }
+    StepTables st;
+    if (!build_step_table(kDcLumBits, kDcVals, true, st.tab[0]) || !build_step_table(kAcLumBits, kAcLumVals, false, st.tab[1]) ||
+        !build_step_table(kDcChrBits, kDcVals, true, st.tab[2]) || !build_step_table(kAcChrBits, kAcChrVals, false, st.tab[3])) {
+        jea_destroy(ctx);
+        return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: Huffman tables do not fit the decode tables");
+    }
+    if ((e = hipMalloc((void**)&ctx->d_steps, sizeof(StepTables))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(ctx->d_steps, &st, sizeof(st), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
     if ((e = hipMalloc((void**)&ctx->d_huff, sizeof(HuffTables))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->d_decode, sizeof(DecodeTables))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->d_status, 64)) != hipSuccess) return bail("hipMalloc", e);
@@ -309,6 +360,7 @@ void jea_destroy(jea_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_decode) (void)hipFree(ctx->d_decode);
+    if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -861,12 +913,12 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.ctx_vals = (uint32_t*)ctx->ctx_vals.ptr;
     sc.ctx_slots = kContextSlots;
     JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
-    JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs,
+    JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
                                        ctx->d_status, follow_up, report));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (with_headers && (rc = headers_ok())) return rc;
     if (report->unsettled != 0)
-        JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, ctx->d_decode, d_coefs, ctx->d_status,
+        JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs, ctx->d_status,
                                            follow_up, report));
     return report_status(ctx, report->status, what);
 }

@@ -183,22 +183,32 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
 // Sub-sequence decoding
 // ---------------------------------------------------------------------------
 
-// The words of one workgroup's 256 sub-sequences plus one more word, MSB-first
-// values, padded by one word per sub-sequence so that threads reading the same
-// word of their own sub-sequences hit different LDS banks.
+// The words of one workgroup's 256 sub-sequences plus a tail, as MSB-first values.  Layout: a dummy
+// word, then the stream words; after every W words one padding word, so that threads reading the
+// same word of their own sub-sequences hit different LDS banks.  Each padding word repeats the word
+// that follows it, which makes any two consecutive words adjacent in LDS: one two-word read fetches
+// the 64 bits around any bit position.
 template <uint32_t W, uint32_t kTail = 1>
 struct GroupWords {
     static constexpr uint32_t kWords = kThreads * W + kTail;   // staged stream words
-    uint32_t w[kWords + kWords / W + 1];
-    __device__ __forceinline__ uint32_t at(uint32_t wi) const { return w[wi + wi / W]; }
+    uint32_t w[(kWords + 1) + (kWords + 1) / W + 2];
+    static __device__ __forceinline__ uint32_t slot(uint32_t index) { return index + index / W; }   // index 0 = the dummy
+    // the 32 stream bits from bit p of the group on
+    __device__ __forceinline__ uint32_t bits(uint32_t p) const {
+        const uint32_t j = (p + 31u) >> 5;          // j-1, j: the stream words that hold them (-1: the dummy, unused)
+        const uint32_t q = slot(j);
+        return __builtin_amdgcn_alignbit(w[q], w[q + 1], 0u - p);
+    }
 };
 
 // first_sub: sub-sequence held by the first slot; negative slots (before the stream) read as zero.
 template <uint32_t W, uint32_t kTail>
 __device__ __forceinline__ void stage_group(GroupWords<W, kTail>& gw, const uint8_t* __restrict__ stream, uint64_t ulen,
                                             int64_t first_sub) {
+    using G = GroupWords<W, kTail>;
     const int64_t first_word = first_sub * (int64_t)W;
-    for (uint32_t i = threadIdx.x; i < GroupWords<W, kTail>::kWords; i += kThreads) {
+    if (threadIdx.x == 0) gw.w[0] = 0;
+    for (uint32_t i = threadIdx.x; i < G::kWords; i += kThreads) {
         const int64_t word = first_word + i;
         const uint64_t byte = (uint64_t)word * 4;
         uint32_t v = 0;
@@ -209,71 +219,94 @@ __device__ __forceinline__ void stage_group(GroupWords<W, kTail>& gw, const uint
             for (int k = 0; k < 4; ++k)
                 if (byte + k < ulen) v |= (uint32_t)stream[byte + k] << (24 - 8 * k);
         }
-        gw.w[i + i / W] = v;
+        const uint32_t index = i + 1, q = G::slot(index);
+        gw.w[q] = v;
+        if (index % W == 0) gw.w[q - 1] = v;   // the padding word before it
+    }
+    if (threadIdx.x == 0) {   // what a read of the last word's neighbour finds
+        const uint32_t q = G::slot(G::kWords);
+        gw.w[q + 1] = 0;
     }
 }
 
-// entropy_encoder.cpp:786-806, 845-864
-__device__ __forceinline__ int amplitude(uint32_t v, uint32_t len, uint32_t ssss) {
-    const uint32_t bits = (v << len) >> (32 - ssss);
-    const uint32_t mask = (1u << ssss) - 1u;
-    if (bits >> (ssss - 1)) return (int)bits;
-    return -(int)(mask & ~bits);
+__device__ __forceinline__ void load_tables(StepTables& t, const StepTables* __restrict__ g) {
+    const uint4* src = reinterpret_cast<const uint4*>(g);
+    uint4* dst = reinterpret_cast<uint4*>(&t);
+    for (uint32_t i = threadIdx.x; i < sizeof(StepTables) / 16; i += kThreads) dst[i] = src[i];
 }
+
+constexpr uint32_t kClassBytes = 2 * sizeof(StepTable);   // luminance tables first, then chrominance
+constexpr uint32_t kAcBytes = sizeof(StepTable);          // DC table first, then AC
+
+// `tab`: the StepTable to use (in LDS), v: the next 32 stream bits.
+__device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v) {
+    uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> 21) & 0x7fcu));
+    if (e == 0) {
+        const StepTable* t = reinterpret_cast<const StepTable*>(tab);
+        const uint32_t idx = (v >> 16) - t->first_long;
+        e = t->slow[idx < (uint32_t)kDecodeSlowEntries ? idx : (uint32_t)kDecodeSlowEntries - 1u];
+    }
+    return e;
+}
+
+// entropy_encoder.cpp:786-806, 845-864: the amplitude whose bits follow a code of `len` bits at the
+// top of v; a leading 1 means the bits are the value, a leading 0 that they are the value's magnitude
+// inverted.  Meaningless when the symbol has no amplitude bits.
+__device__ __forceinline__ int step_amplitude(uint32_t v, uint32_t e) {
+    const uint32_t x = v << ((e >> 16) & 31u);
+    const uint32_t sg = (uint32_t)((int32_t)x >> 31);          // all ones: value is positive
+    const uint32_t y = ~(x ^ sg) >> ((e >> 24) & 31u);          // positive: the bits; negative: their complement
+    return (int)(~(y ^ sg) + sg + 1u);
+}
+
+__device__ __forceinline__ uint32_t class_offset(uint32_t lum_mask, uint32_t c) {
+    return ((lum_mask >> c) & 1u) ? 0u : kClassBytes;
+}
+__device__ __forceinline__ uint32_t next_channel(uint32_t c) { return c == 2u ? 0u : c + 1u; }
 
 // Decode from `state` (of sub-sequence `sub` of the staged group) to the first
 // symbol boundary at or past the end of the sub-sequence, counting the blocks
 // completed and summing the DC differences met.  Malformed symbols do not stop
-// the walk (one bit is skipped), so that a walk from a wrong guess always ends.
+// the walk (they count as one bit and one coefficient), so every walk ends.
+//
+// The loop body has no branches.  What depends on the channel -- table class, DC sum -- is kept in
+// three registers each, rotated when a block ends, so that the current channel's is always the first.
 template <uint32_t W>
-__device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTables& t, uint32_t lum_mask,
+__device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTables& t, uint32_t lum_mask,
                                          uint32_t sub, uint32_t state, Sums& sums) {
     constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
-    uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
+    const uint32_t c0 = (state >> 8) & 3u;
+    uint32_t z = (state >> 16) & 63u;
     const uint32_t end = (sub + 1) * kSubBits;
-    int nb = 0, dc0 = 0, dc1 = 0, dc2 = 0;
-    uint32_t wi = p >> 5;
-    uint32_t hi = gw.at(wi), lo = gw.at(wi + 1);
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(&t);
+    const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
+    uint32_t o0 = class_offset(lum_mask, c0), o1 = class_offset(lum_mask, c1), o2 = class_offset(lum_mask, c2);
+    uint32_t k = z ? kAcBytes : 0u;     // DC table at the start of a block, AC table inside
+    int nb = 0, a0 = 0, a1 = 0, a2 = 0;
     while (p < end) {
-        if ((p >> 5) != wi) {
-            wi = p >> 5;
-            hi = gw.at(wi);
-            lo = gw.at(wi + 1);
-        }
-        const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) << (p & 31u) >> 32);
-        // One path for DC and AC symbols: the threads of a wave are in different
-        // places of their blocks, so separate branches would both run every time.
-        const bool is_dc = z == 0;
-        const uint32_t e = huff_entry(t.tab[(((lum_mask >> c) & 1u) ? 0u : 2u) + (is_dc ? 0u : 1u)], v >> 16);
-        const uint32_t len = e >> 8, sym = e & 0xffu;
-        const uint32_t ss = is_dc ? sym : (sym & 15u);     // amplitude bits that follow the code word
-        const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
-        if (bad) {
-            p += 1;
-            continue;
-        }
-        p += len + ss;
-        bool block_done = false;
-        if (is_dc) {
-            const int diff = ss ? amplitude(v, len, ss) : 0;
-            dc0 += (c == 0) ? diff : 0;
-            dc1 += (c == 1) ? diff : 0;
-            dc2 += (c == 2) ? diff : 0;
-            z = 1;
-        } else {
-            const uint32_t processed = z + (sym >> 4);   // AC positions consumed including this entry
-            if (sym == 0x00 || processed >= 63) block_done = true;
-            else z = processed + 1;
-        }
-        if (block_done) {
-            z = 0;
-            c = (c == 2) ? 0 : c + 1;
-            ++nb;
-        }
+        const uint32_t v = gw.bits(p);
+        const uint32_t e = step_lookup(tb + o0 + k, v);
+        p += e & 0xffu;
+        const uint32_t processed = z + ((e >> 8) & 0xffu);   // AC positions consumed including this entry
+        const bool done = processed >= 63u;                  // end of block, or the block is full
+        z = done ? 0u : processed + 1u;
+        k = done ? 0u : kAcBytes;
+        a0 += ((int32_t)e < 0) ? step_amplitude(v, e) : 0;   // kStepDcAdd
+        nb += done ? 1 : 0;
+        const uint32_t o = o0;
+        const int a = a0;
+        o0 = done ? o1 : o0; o1 = done ? o2 : o1; o2 = done ? o : o2;
+        a0 = done ? a1 : a0; a1 = done ? a2 : a1; a2 = done ? a : a2;
     }
-    sums = Sums{nb, dc0, dc1, dc2};
-    return make_state(p >= end ? p - end : 0, c, z);
+    // (a0, a1, a2) belong to the channel the walk ended in and the two after it
+    const uint32_t turns = (uint32_t)nb % 3u;
+    const uint32_t c_end = (c0 + turns) % 3u;
+    const int d0 = c_end == 0 ? a0 : (c_end == 1 ? a2 : a1);
+    const int d1 = c_end == 1 ? a0 : (c_end == 2 ? a2 : a1);
+    const int d2 = c_end == 2 ? a0 : (c_end == 0 ? a2 : a1);
+    sums = Sums{nb, d0, d1, d2};
+    return make_state(p - end, c_end, z);
 }
 
 // ---------------------------------------------------------------------------
@@ -281,9 +314,9 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
 // thread decodes it to its end, also past the end of the sub-sequence (at most
 // 1660 bits, which the staged window covers), and the thread after it skips the
 // part it finds itself in.  So every block is produced by exactly one thread,
-// which assembles it in registers 16 bytes (8 zig-zag positions) at a time and
-// stores whole chunks: no zero-filled output is needed and no two threads ever
-// write to the same block.
+// which assembles it 16 bytes (8 zig-zag positions) at a time in a small LDS
+// buffer of its own and stores whole chunks: no zero-filled output is needed and
+// no two threads ever write to the same block.
 //
 // Output layouts: kPlanar = false: [block][64] int16, all eight chunks of every
 // block are stored.  kPlanar = true (inside the library): chunk c of block
@@ -293,6 +326,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const DecodeTa
 // ---------------------------------------------------------------------------
 
 constexpr uint32_t kWriteTail = 56;   // words staged past the group: 1660 bits of overrun + 64 bits of look-ahead
+constexpr uint32_t kAccWords = 6;     // per-thread chunk buffer: 16 bytes + padding against bank conflicts
 
 struct WriteTarget {
     int16_t* out;            // coefficients of this image
@@ -308,11 +342,11 @@ struct WriteTarget {
 
 template <bool kPlanar>
 struct BlockWriter {
+    uint32_t* acc;       // this thread's chunk buffer in LDS, all zero between chunks
     uint4* dst;          // chunk 0 of the current block
     size_t chunk_stride; // in 16-byte units
     uint8_t* mask_dst;
-    uint32_t a0, a1, a2, a3;   // the chunk being assembled
-    uint32_t chunk;            // its index
+    uint32_t chunk;      // index of the chunk being assembled
     uint32_t mask;
 
     __device__ __forceinline__ void begin(const WriteTarget& wt, uint32_t block) {
@@ -325,14 +359,18 @@ struct BlockWriter {
             dst = reinterpret_cast<uint4*>(wt.out) + (size_t)block * 8;
             chunk_stride = 1;
         }
-        a0 = a1 = a2 = a3 = 0;
         chunk = 0;
         mask = 0;
     }
     __device__ __forceinline__ void flush() {
-        const bool nonzero = (a0 | a1 | a2 | a3) != 0;
-        if (!kPlanar || chunk == 0 || nonzero) dst[chunk * chunk_stride] = make_uint4(a0, a1, a2, a3);
-        mask |= (nonzero ? 1u : 0u) << chunk;
+        const uint2 lo = *reinterpret_cast<const uint2*>(acc), hi = *reinterpret_cast<const uint2*>(acc + 2);
+        const bool nonzero = (lo.x | lo.y | hi.x | hi.y) != 0;
+        if (!kPlanar || chunk == 0 || nonzero) dst[chunk * chunk_stride] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (nonzero) {
+            *reinterpret_cast<uint2*>(acc) = make_uint2(0, 0);
+            *reinterpret_cast<uint2*>(acc + 2) = make_uint2(0, 0);
+            mask |= 1u << chunk;
+        }
     }
     // positions arrive in increasing order
     __device__ __forceinline__ void put(uint32_t position, int value) {
@@ -342,14 +380,8 @@ struct BlockWriter {
             if (!kPlanar)
                 for (uint32_t i = chunk + 1; i < c; ++i) dst[i] = make_uint4(0, 0, 0, 0);
             chunk = c;
-            a0 = a1 = a2 = a3 = 0;
         }
-        const uint32_t v = ((uint32_t)value & 0xffffu) << (16u * (position & 1u));
-        const uint32_t word = (position >> 1) & 3u;
-        a0 |= word == 0 ? v : 0u;
-        a1 |= word == 1 ? v : 0u;
-        a2 |= word == 2 ? v : 0u;
-        a3 |= word == 3 ? v : 0u;
+        reinterpret_cast<int16_t*>(acc)[position & 7u] = (int16_t)value;
     }
     __device__ __forceinline__ void end() {
         flush();
@@ -361,78 +393,63 @@ struct BlockWriter {
     }
 };
 
+// Every symbol moves the position inside the block forward, so a block is at most 64 symbols of at
+// most 26 bits (a damaged one included) and the walk cannot leave the staged window.
 template <uint32_t W, bool kPlanar>
-__device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw, const DecodeTables& t,
+__device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw, const StepTables& t, uint32_t* acc,
                                              uint32_t lum_mask, uint32_t sub, uint32_t state, WriteTarget& wt) {
     constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
-    uint32_t c = (state >> 8) & 3u, z = (state >> 16) & 63u;
+    const uint32_t c0 = (state >> 8) & 3u;
+    uint32_t z = (state >> 16) & 63u;
     const uint32_t end = (sub + 1) * kSubBits;
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(&t);
+    const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
+    // table class and running DC of the current channel and the two after it (see walk)
+    uint32_t o0 = class_offset(lum_mask, c0), o1 = class_offset(lum_mask, c1), o2 = class_offset(lum_mask, c2);
+    int l0 = c0 == 0 ? wt.last0 : (c0 == 1 ? wt.last1 : wt.last2);
+    int l1 = c1 == 0 ? wt.last0 : (c1 == 1 ? wt.last1 : wt.last2);
+    int l2 = c2 == 0 ? wt.last0 : (c2 == 1 ? wt.last1 : wt.last2);
+    uint32_t k = z ? kAcBytes : 0u;
     uint32_t block = wt.block;
-    int last0 = wt.last0, last1 = wt.last1, last2 = wt.last2;
-    bool error = false, finished = false, owning = false;
+    bool finished = false, owning = false;
     uint32_t final_bit = 0;
+    uint32_t trouble = 0;   // bit 6: an entry reaches past position 63; kStepBad: no code word -- in an own block
     BlockWriter<kPlanar> bw;
-    uint32_t wi = p >> 5;
-    uint32_t hi = gw.at(wi), lo = gw.at(wi + 1);
+    bw.acc = acc;
     for (;;) {
-        if (z == 0 && !owning) {
+        if (k == 0 && !owning) {
             // at a block boundary: the block that starts here is this thread's, if it starts in its sub-sequence
             if (p >= end) break;
             owning = true;
             bw.begin(wt, block);
         }
-        if ((p >> 5) != wi) {
-            wi = p >> 5;
-            hi = gw.at(wi);
-            lo = gw.at(wi + 1);
-        }
-        const uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) << (p & 31u) >> 32);
-        const bool is_dc = z == 0;
-        const uint32_t e = huff_entry(t.tab[(((lum_mask >> c) & 1u) ? 0u : 2u) + (is_dc ? 0u : 1u)], v >> 16);
-        const uint32_t len = e >> 8, sym = e & 0xffu;
-        const uint32_t ss = is_dc ? sym : (sym & 15u);
-        const bool bad = e == 0 || ss > (is_dc ? 11u : 10u) || (!is_dc && ss == 0 && sym != 0x00 && sym != 0xF0);
-        if (bad) {
-            // the serial decoder stops here; the owner of the block reports it
-            error |= owning;
-            p += 1;
-            // a damaged stream must not keep a thread walking for ever: give the block up at the window's end
-            if (p >= kThreads * kSubBits + 32 * (kWriteTail - 2)) {
-                if (owning) bw.end();
-                break;
-            }
-            continue;
-        }
-        p += len + ss;
-        bool block_done = false;
-        if (is_dc) {
-            const int diff = ss ? amplitude(v, len, ss) : 0;
-            if (owning) {
-                // entropy_encoder.cpp:125-126: the DC chain runs in int16
-                const int prev = c == 0 ? last0 : (c == 1 ? last1 : last2);
-                const int dc = (int)(int16_t)(prev + diff);
-                last0 = c == 0 ? dc : last0;
-                last1 = c == 1 ? dc : last1;
-                last2 = c == 2 ? dc : last2;
-                bw.put(0, dc);
-            }
-            z = 1;
-        } else {
-            const uint32_t processed = z + (sym >> 4);   // AC positions consumed including this entry
-            if (sym == 0x00 || processed >= 63) {
-                // EOB, or the block is full: then this entry, being the last, is dropped
-                // (entropy_encoder.cpp:129); more than 63 is a stream error for the serial decoder
-                if (sym != 0x00 && processed > 63) error |= owning;
-                block_done = true;
-            } else {
-                if (ss && owning) bw.put(processed, amplitude(v, len, ss));
-                z = processed + 1;
+        const uint32_t v = gw.bits(p);
+        const uint32_t e = step_lookup(tb + o0 + k, v);
+        const bool is_dc = k == 0;
+        p += e & 0xffu;
+        // AC positions consumed including this entry; the end-of-block symbol counts as kStepRunEob,
+        // so values 64..127 can only come from an entry that does not fit: the serial decoder's error
+        const uint32_t processed = z + ((e >> 8) & 0xffu);
+        const bool done = processed >= 63u;
+        z = done ? 0u : processed + 1u;
+        k = done ? 0u : kAcBytes;
+        if (owning) {
+            const int amp = (e & kStepHasAmp) ? step_amplitude(v, e) : 0;
+            trouble |= processed | (e & kStepBad);
+            if (is_dc) {
+                l0 = (int)(int16_t)(l0 + amp);   // entropy_encoder.cpp:125-126: the DC chain runs in int16
+                bw.put(0, l0);
+            } else if (!done && (e & kStepHasAmp)) {
+                // an entry that completes the block is the last one and is dropped (entropy_encoder.cpp:129)
+                bw.put(processed, amp);
             }
         }
-        if (block_done) {
-            z = 0;
-            c = (c == 2) ? 0 : c + 1;
+        if (done) {
+            const uint32_t o = o0;
+            const int l = l0;
+            o0 = o1; o1 = o2; o2 = o;
+            l0 = l1; l1 = l2; l2 = l;
             if (owning) bw.end();
             owning = false;
             if (++block == wt.total_blocks) {
@@ -441,12 +458,8 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
                 break;
             }
         }
-        if (p >= kThreads * kSubBits + 32 * (kWriteTail - 2)) {   // cannot happen in a well-formed stream
-            if (owning) { bw.end(); error = true; }
-            break;
-        }
     }
-    wt.error = error;
+    wt.error = (trouble & (64u | kStepBad)) != 0;
     wt.finished = finished;
     wt.final_bit = final_bit;
 }
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                const uint64_t* __restrict__ sizes,
                                                                const uint64_t* __restrict__ img_drops,
                                                                uint32_t n_groups, int first_round,
-                                                               const DecodeTables* __restrict__ tables,
+                                                               const StepTables* __restrict__ tables,
                                                                uint32_t* __restrict__ sub_end,
                                                                uint32_t* __restrict__ sub_used,
                                                                int4* __restrict__ sub_info,
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                uint32_t* __restrict__ changed) {
     constexpr uint32_t kSubBits = 32 * W;
     __shared__ GroupWords<W> gw;
-    __shared__ DecodeTables t;
+    __shared__ StepTables t;
     __shared__ uint32_t ends[kThreads + 1];   // ends[i] = state at the start of the sub-sequence in slot i
     __shared__ Sums red[4];
 
@@ -530,8 +543,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         if (tid == 0) ends[0] = 0;
     }
 
-    for (uint32_t i = tid; i < sizeof(DecodeTables) / 4; i += kThreads)
-        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
+    load_tables(t, tables);
     stage_group(gw, ustream + ubase[img], ulen, first_sub);
     __syncthreads();
 
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const uint64_t* __restrict__ sizes,
                                                                 const uint64_t* __restrict__ img_drops,
                                                                 uint32_t n_groups, uint32_t total_blocks,
-                                                                const DecodeTables* __restrict__ tables,
+                                                                const StepTables* __restrict__ tables,
                                                                 const uint32_t* __restrict__ sub_used,
                                                                 const int4* __restrict__ sub_info,
                                                                 const int4* __restrict__ grp_base,
@@ -718,8 +730,9 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 int32_t* __restrict__ status) {
     constexpr uint32_t kSubBits = 32 * W;
     __shared__ GroupWords<W, kWriteTail> gw;
-    __shared__ DecodeTables t;
+    __shared__ StepTables t;
     __shared__ Sums lds4[4];
+    __shared__ __align__(8) uint32_t acc[kThreads * kAccWords];
 
     const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const uint64_t ulen = sizes[img] - img_drops[img];
@@ -732,10 +745,10 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     const uint64_t first_bit = ((uint64_t)group * kOwned + tid) * kSubBits;
     const bool active = tid < kOwned && first_bit < total_bits;
 
-    for (uint32_t i = tid; i < sizeof(DecodeTables) / 4; i += kThreads)
-        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
+    load_tables(t, tables);
     const uint8_t* stream = ustream + ubase[img];
     stage_group(gw, stream, ulen, (int64_t)group * kOwned);
+    for (uint32_t i = 0; i < kAccWords; ++i) acc[tid * kAccWords + i] = 0;
 
     const int4 si = tid < kOwned ? sub_info[sub_index] : make_int4(0, 0, 0, 0);
     Sums total;
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     wt.final_bit = 0;
     if (!active || wt.block >= total_blocks) return;
 
-    write_blocks<W, kPlanar>(gw, t, lum_mask, tid, sub_used[sub_index], wt);
+    write_blocks<W, kPlanar>(gw, t, acc + tid * kAccWords, lum_mask, tid, sub_used[sub_index], wt);
     if (wt.error) {
         // a malformed symbol outranks a missing end marker, as in the serial order of checks
         const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
@@ -851,7 +864,7 @@ struct DecodeRun {
     const uint64_t* d_sizes;
     const DecodePlan& p;
     const DecodeScratch& sc;
-    const DecodeTables* d_tables;
+    const StepTables* d_tables;
     int16_t* d_coefs;
     int32_t* d_status;
 
@@ -932,7 +945,7 @@ struct DecodeRun {
 
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
-                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const std::function<void()>& follow_up, DecodeReport* report) {
     hipError_t e;
     const dim3 cgrid(p.n_chunks, p.n_images);
@@ -952,7 +965,7 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
 }
 
 hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
-                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const std::function<void()>& follow_up, DecodeReport* report) {
     switch (p.sub_words) {
         case kSubWordsSmall:

@@ -45,6 +45,30 @@ struct DecodeTables {
     DecodeTable tab[4];
 };
 
+// The same four tables for the parallel decoder, whose inner loop wants everything about a symbol in
+// one word so that it needs no branches:
+//   byte 0  bits the symbol takes from the stream: code length + amplitude bits (1 when no code matches)
+//   byte 1  coefficient positions skipped before the value: the run of an AC symbol, 0 for DC symbols,
+//           kStepRunEob for the end-of-block symbol (far more than a block has)
+//   byte 2  code length
+//   byte 3  bits 0-4: 32 - amplitude bits (the shift that brings the amplitude down from the top of a word);
+//           kStepHasAmp, kStepBad, kStepDcAdd flags
+// fast[] is indexed by the next 9 stream bits (0 = a longer code, look in slow[]), slow[] by
+// (next 16 bits) - first_long, as in DecodeTable.
+constexpr uint32_t kStepRunEob = 127;
+constexpr uint32_t kStepHasAmp = 1u << 29;   // amplitude bits follow the code
+constexpr uint32_t kStepBad = 1u << 30;      // no code word, or a symbol the format does not allow
+constexpr uint32_t kStepDcAdd = 1u << 31;    // DC symbol with amplitude bits (the sign bit: one compare)
+struct StepTable {
+    uint32_t fast[512];
+    uint32_t slow[kDecodeSlowEntries];
+    uint32_t first_long;
+    uint32_t pad[3];
+};
+struct StepTables {
+    StepTable tab[4];
+};
+
 // Which of the reference's colour mappers the components come from (colour_mapping.cpp):
 // RGBToYCbCrMapper -- the transform of :44-92, component 0 is the only luminance component (:94-97);
 // RGBToRGBMapper   -- components are R, G, B as they are (:16-37) and all three count as luminance
@@ -188,13 +212,13 @@ struct DecodeReport {
 // repair_entropy_decode has to run.
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
-                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const std::function<void()>& follow_up, DecodeReport* report);
 
 // For streams that the standard rounds did not settle: more rounds (waiting on the stream after each),
 // then the write pass, `follow_up` and the report again, and a final wait.
 hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
-                                 const DecodeTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const std::function<void()>& follow_up, DecodeReport* report);
 
 // Copies the header_bytes bytes in front of each scan (d_scan_offsets[i] is the scan's offset in
