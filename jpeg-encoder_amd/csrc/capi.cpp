@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -139,13 +140,14 @@ bool build_decode_table(const uint8_t bits[16], const uint8_t* vals, DecodeTable
     return true;
 }
 
-// The parallel decoder's view of the same code (kernels.h, StepTable).
-bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, StepTable& t) {
-    const uint32_t bad = kStepBad | (0u << 16) | (0u << 8) | 1u;   // skip one bit, keep going
+// The parallel decoder's view of the same code (kernels.h, StepTableT).
+template <class Table>
+bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, Table& t) {
+    constexpr uint32_t F = Table::kFastBits, kSub = 1u << (16 - F);   // sub-table: one entry per 16-bit prefix
+    const uint32_t bad = kStepBad | 1u;   // skip one bit, keep going
     for (uint32_t& e : t.fast) e = bad;
     for (uint32_t& e : t.slow) e = bad;
-    t.first_long = 65536;
-    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    uint32_t first_bucket = 1u << F;      // first fast index that is resolved through slow[]
     uint32_t code = 0;
     int k = 0;
     for (uint32_t l = 1; l <= 16; ++l) {
@@ -161,23 +163,26 @@ bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, S
                 entry = (l + ss) | (run_code << 8) | (l << 16) | (((32u - ss) & 31u) << 24);
                 if (ss) entry |= kStepHasAmp | (is_dc ? kStepDcAdd : 0u);
             }
-            if (l <= 9) {
-                const uint32_t first = code << (9 - l);
-                for (uint32_t j = 0; j < (1u << (9 - l)); ++j) t.fast[first + j] = entry;
+            if (l <= F) {
+                const uint32_t first = code << (F - l);
+                for (uint32_t j = 0; j < (1u << (F - l)); ++j) t.fast[first + j] = entry;
             } else {
-                const uint32_t first = code << (16 - l);
-                if (t.first_long == 65536) t.first_long = first;
-                if (first + (1u << (16 - l)) - t.first_long > (uint32_t)kDecodeSlowEntries) return false;
-                for (uint32_t j = 0; j < (1u << (16 - l)); ++j) t.slow[first + j - t.first_long] = entry;
+                const uint32_t first = code << (16 - l);   // as a 16-bit prefix
+                if (first_bucket == (1u << F)) first_bucket = first >> (16 - F);
+                // canonical codes grow with their length: everything from here up goes through slow[]
+                const uint32_t at = first - (first_bucket << (16 - F));
+                if (at + (1u << (16 - l)) > (uint32_t)Table::kSlowEntries) return false;
+                for (uint32_t j = 0; j < (1u << (16 - l)); ++j) t.slow[at + j] = entry;
             }
             ++code;
         }
         code <<= 1;
     }
-    // every prefix from the first long code word on is resolved through slow[] (0 = "look there"),
-    // the ones above the last code word included
-    if (t.first_long != 65536)
-        for (uint32_t j = t.first_long >> 7; j < 512; ++j) t.fast[j] = 0;
+    if (((1u << F) - first_bucket) * kSub > (uint32_t)Table::kSlowEntries) return false;
+    for (uint32_t j = first_bucket; j < (1u << F); ++j) {
+        const uint32_t offset = (uint32_t)offsetof(Table, slow) + (j - first_bucket) * kSub * 4u;
+        t.fast[j] = ((kSub - 1u) << 8) | (offset << 16);
+    }
     return true;
 }
 
@@ -328,8 +333,8 @@ int jea_create(int device_id, jea_ctx** out_ctx) {
         return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: Huffman tables do not fit the decode tables");
     }
     StepTables st;
-    if (!build_step_table(kDcLumBits, kDcVals, true, st.tab[0]) || !build_step_table(kAcLumBits, kAcLumVals, false, st.tab[1]) ||
-        !build_step_table(kDcChrBits, kDcVals, true, st.tab[2]) || !build_step_table(kAcChrBits, kAcChrVals, false, st.tab[3])) {
+    if (!build_step_table(kDcLumBits, kDcVals, true, st.cls[0].dc) || !build_step_table(kAcLumBits, kAcLumVals, false, st.cls[0].ac) ||
+        !build_step_table(kDcChrBits, kDcVals, true, st.cls[1].dc) || !build_step_table(kAcChrBits, kAcChrVals, false, st.cls[1].ac)) {
         jea_destroy(ctx);
         return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: Huffman tables do not fit the decode tables");
     }

@@ -185,20 +185,14 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
 
 // The words of one workgroup's 256 sub-sequences plus a tail, as MSB-first values.  Layout: a dummy
 // word, then the stream words; after every W words one padding word, so that threads reading the
-// same word of their own sub-sequences hit different LDS banks.  Each padding word repeats the word
-// that follows it, which makes any two consecutive words adjacent in LDS: one two-word read fetches
-// the 64 bits around any bit position.
-template <uint32_t W, uint32_t kTail = 1>
+// same word of their own sub-sequences hit different LDS banks.
+// kTail: words staged past the group; the window below looks three words past the one that holds the
+// last bit of a sub-sequence.
+template <uint32_t W, uint32_t kTail = 3>
 struct GroupWords {
     static constexpr uint32_t kWords = kThreads * W + kTail;   // staged stream words
-    uint32_t w[(kWords + 1) + (kWords + 1) / W + 2];
+    uint32_t w[(kWords + 1) + (kWords + 1) / W + 1];
     static __device__ __forceinline__ uint32_t slot(uint32_t index) { return index + index / W; }   // index 0 = the dummy
-    // the 32 stream bits from bit p of the group on
-    __device__ __forceinline__ uint32_t bits(uint32_t p) const {
-        const uint32_t j = (p + 31u) >> 5;          // j-1, j: the stream words that hold them (-1: the dummy, unused)
-        const uint32_t q = slot(j);
-        return __builtin_amdgcn_alignbit(w[q], w[q + 1], 0u - p);
-    }
 };
 
 // first_sub: sub-sequence held by the first slot; negative slots (before the stream) read as zero.
@@ -219,33 +213,50 @@ __device__ __forceinline__ void stage_group(GroupWords<W, kTail>& gw, const uint
             for (int k = 0; k < 4; ++k)
                 if (byte + k < ulen) v |= (uint32_t)stream[byte + k] << (24 - 8 * k);
         }
-        const uint32_t index = i + 1, q = G::slot(index);
-        gw.w[q] = v;
-        if (index % W == 0) gw.w[q - 1] = v;   // the padding word before it
-    }
-    if (threadIdx.x == 0) {   // what a read of the last word's neighbour finds
-        const uint32_t q = G::slot(G::kWords);
-        gw.w[q + 1] = 0;
+        gw.w[G::slot(i + 1)] = v;
     }
 }
 
+// The 64 stream bits around the read position, in registers, and the word after them on its way from
+// LDS: the next symbol's bits never wait for a load.  With j = ceil(p / 32), `a` and `b` are stream
+// words j-1 and j (word -1 being the dummy), which hold bits p .. p+31 for every p with that j.
+template <class Group>
+struct BitWindow {
+    const Group& gw;
+    uint32_t j, a, b, n;
+    __device__ __forceinline__ BitWindow(const Group& g, uint32_t p) : gw(g) {
+        j = (p + 31u) >> 5;
+        a = gw.w[Group::slot(j)];
+        b = gw.w[Group::slot(j + 1)];
+        n = gw.w[Group::slot(j + 2)];
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t p) const { return __builtin_amdgcn_alignbit(a, b, 0u - p); }
+    // p has moved on by less than 32 bits
+    __device__ __forceinline__ void follow(uint32_t p) {
+        const uint32_t j2 = (p + 31u) >> 5;
+        const bool crossed = j2 != j;
+        a = crossed ? b : a;
+        b = crossed ? n : b;
+        j = j2;
+        n = gw.w[Group::slot(j2 + 2)];
+    }
+};
+
 __device__ __forceinline__ void load_tables(StepTables& t, const StepTables* __restrict__ g) {
+    static_assert(sizeof(StepTables) % 16 == 0, "copied in 16-byte pieces");
     const uint4* src = reinterpret_cast<const uint4*>(g);
     uint4* dst = reinterpret_cast<uint4*>(&t);
     for (uint32_t i = threadIdx.x; i < sizeof(StepTables) / 16; i += kThreads) dst[i] = src[i];
 }
 
-constexpr uint32_t kClassBytes = 2 * sizeof(StepTable);   // luminance tables first, then chrominance
-constexpr uint32_t kAcBytes = sizeof(StepTable);          // DC table first, then AC
+constexpr uint32_t kClassBytes = sizeof(StepClass);    // luminance tables first, then chrominance
+constexpr uint32_t kAcBytes = sizeof(StepTableDc);     // DC table first, then AC
+constexpr uint32_t kDcShift = 32 - StepTableDc::kFastBits, kAcShift = 32 - StepTableAc::kFastBits;
 
-// `tab`: the StepTable to use (in LDS), v: the next 32 stream bits.
-__device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v) {
-    uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> 21) & 0x7fcu));
-    if (e == 0) {
-        const StepTable* t = reinterpret_cast<const StepTable*>(tab);
-        const uint32_t idx = (v >> 16) - t->first_long;
-        e = t->slow[idx < (uint32_t)kDecodeSlowEntries ? idx : (uint32_t)kDecodeSlowEntries - 1u];
-    }
+// `tab`: the table to use (in LDS), v: the next 32 stream bits, shift: 32 - the table's fast bits.
+__device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v, uint32_t shift) {
+    uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> shift) << 2));
+    if ((e & 0xffu) == 0) e = *reinterpret_cast<const uint32_t*>(tab + (e >> 16) + (((v >> 16) & ((e >> 8) & 0xffu)) << 2));
     return e;
 }
 
@@ -283,15 +294,19 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
     const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
     uint32_t o0 = class_offset(lum_mask, c0), o1 = class_offset(lum_mask, c1), o2 = class_offset(lum_mask, c2);
     uint32_t k = z ? kAcBytes : 0u;     // DC table at the start of a block, AC table inside
+    uint32_t shift = z ? kAcShift : kDcShift;
     int nb = 0, a0 = 0, a1 = 0, a2 = 0;
+    BitWindow<GroupWords<W>> win(gw, p);
     while (p < end) {
-        const uint32_t v = gw.bits(p);
-        const uint32_t e = step_lookup(tb + o0 + k, v);
+        const uint32_t v = win.peek(p);
+        const uint32_t e = step_lookup(tb + o0 + k, v, shift);
         p += e & 0xffu;
+        win.follow(p);
         const uint32_t processed = z + ((e >> 8) & 0xffu);   // AC positions consumed including this entry
         const bool done = processed >= 63u;                  // end of block, or the block is full
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
+        shift = done ? kDcShift : kAcShift;
         a0 += ((int32_t)e < 0) ? step_amplitude(v, e) : 0;   // kStepDcAdd
         nb += done ? 1 : 0;
         const uint32_t o = o0;
@@ -325,7 +340,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
 // stored, and one mask byte per block says which chunks are non-zero.
 // ---------------------------------------------------------------------------
 
-constexpr uint32_t kWriteTail = 56;   // words staged past the group: 1660 bits of overrun + 64 bits of look-ahead
+constexpr uint32_t kWriteTail = 56;   // words staged past the group: 1660 bits of overrun + 96 bits of look-ahead
 constexpr uint32_t kAccWords = 6;     // per-thread chunk buffer: 16 bytes + padding against bank conflicts
 
 struct WriteTarget {
@@ -411,12 +426,14 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     int l1 = c1 == 0 ? wt.last0 : (c1 == 1 ? wt.last1 : wt.last2);
     int l2 = c2 == 0 ? wt.last0 : (c2 == 1 ? wt.last1 : wt.last2);
     uint32_t k = z ? kAcBytes : 0u;
+    uint32_t shift = z ? kAcShift : kDcShift;
     uint32_t block = wt.block;
     bool finished = false, owning = false;
     uint32_t final_bit = 0;
     uint32_t trouble = 0;   // bit 6: an entry reaches past position 63; kStepBad: no code word -- in an own block
     BlockWriter<kPlanar> bw;
     bw.acc = acc;
+    BitWindow<GroupWords<W, kWriteTail>> win(gw, p);
     for (;;) {
         if (k == 0 && !owning) {
             // at a block boundary: the block that starts here is this thread's, if it starts in its sub-sequence
@@ -424,16 +441,18 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
             owning = true;
             bw.begin(wt, block);
         }
-        const uint32_t v = gw.bits(p);
-        const uint32_t e = step_lookup(tb + o0 + k, v);
+        const uint32_t v = win.peek(p);
+        const uint32_t e = step_lookup(tb + o0 + k, v, shift);
         const bool is_dc = k == 0;
         p += e & 0xffu;
+        win.follow(p);
         // AC positions consumed including this entry; the end-of-block symbol counts as kStepRunEob,
         // so values 64..127 can only come from an entry that does not fit: the serial decoder's error
         const uint32_t processed = z + ((e >> 8) & 0xffu);
         const bool done = processed >= 63u;
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
+        shift = done ? kDcShift : kAcShift;
         if (owning) {
             const int amp = (e & kStepHasAmp) ? step_amplitude(v, e) : 0;
             trouble |= processed | (e & kStepBad);

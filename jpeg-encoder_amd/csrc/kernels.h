@@ -53,20 +53,27 @@ struct DecodeTables {
 //   byte 2  code length
 //   byte 3  bits 0-4: 32 - amplitude bits (the shift that brings the amplitude down from the top of a word);
 //           kStepHasAmp, kStepBad, kStepDcAdd flags
-// fast[] is indexed by the next 9 stream bits (0 = a longer code, look in slow[]), slow[] by
-// (next 16 bits) - first_long, as in DecodeTable.
+// fast[] is indexed by the next kFastBits stream bits.  Where longer codes start with those bits the entry
+// has byte 0 = 0 and points to a sub-table of slow[] indexed by the stream bits that follow:
+//   byte 1  mask for those bits (sub-table size - 1),  bytes 2-3  byte offset of the sub-table in the table
 constexpr uint32_t kStepRunEob = 127;
 constexpr uint32_t kStepHasAmp = 1u << 29;   // amplitude bits follow the code
 constexpr uint32_t kStepBad = 1u << 30;      // no code word, or a symbol the format does not allow
 constexpr uint32_t kStepDcAdd = 1u << 31;    // DC symbol with amplitude bits (the sign bit: one compare)
-struct StepTable {
-    uint32_t fast[512];
-    uint32_t slow[kDecodeSlowEntries];
-    uint32_t first_long;
-    uint32_t pad[3];
+template <int kFastBitsT, int kSlowEntriesT>
+struct StepTableT {
+    static constexpr int kFastBits = kFastBitsT, kSlowEntries = kSlowEntriesT;
+    uint32_t fast[1 << kFastBitsT];
+    uint32_t slow[kSlowEntriesT];
+};
+using StepTableDc = StepTableT<9, 128>;    // DC codes are at most 11 bits long
+using StepTableAc = StepTableT<11, 256>;   // the Annex K AC codes beyond 11 bits fit eight 32-entry sub-tables
+struct StepClass {
+    StepTableDc dc;
+    StepTableAc ac;
 };
 struct StepTables {
-    StepTable tab[4];
+    StepClass cls[2];   // luminance, chrominance
 };
 
 // Which of the reference's colour mappers the components come from (colour_mapping.cpp):
