@@ -159,6 +159,31 @@ __device__ __forceinline__ void colour_inverse(int Y, int Cb, int Cr, uint8_t& r
     b = (uint8_t)round_to_range(y + 1.772 * cb);
 }
 
+// The same three formulas in exact arithmetic, by the method of colour_forward_shifted_fast.  With
+// cb = Cb - 128, cr = Cr - 128:
+//   R = floor((1000 Y + 1402 cr + 500) / 1000)          B likewise with 1772 cb
+//   G = Y + floor((62500 - 43017 cb - 89267 cr) / 125000)     (0.344136 = 43017/125000, 0.714136 = 89267/125000;
+//                                                              Y is an integer and may leave the floor)
+// wherever the reference's double arithmetic, whose error is some 1e-13, cannot land on the other side of
+// an integer, i.e. everywhere but at numerators that are multiples of M (ties).  Numerators are built by
+// exact FMAs with d*M added (0.125 for M = 1000; 5 for M = 125000, where the corner |cb|, |cr| ~ 128 passes
+// 2^24 and may be off by one unit: that is 8e-6 of a quotient and counted in the margin), divided by a
+// multiply with RN(1/M) -- quotients up to 482 resp. 136 in magnitude, so within 5.8e-5 resp. 2.5e-5 of the
+// true (t / M) + d, both below d = 1.25e-4 resp. 4e-5 -- and flagged when fract(q) < 2d.  Unflagged,
+// floor(q) = floor(t / M).  Values still need the clamp to [0, 255] (:49-51).
+__device__ __forceinline__ void colour_inverse_fast(float Y, float Cb, float Cr, float& r, float& g, float& b, bool& tie) {
+    const float cb = Cb - 128.0f, cr = Cr - 128.0f;
+    const float y1000 = __builtin_fmaf(1000.0f, Y, 500.125f);
+    const float qr = __builtin_fmaf(1402.0f, cr, y1000) * (1.0f / 1000.0f);
+    const float qb = __builtin_fmaf(1772.0f, cb, y1000) * (1.0f / 1000.0f);
+    const float qg = __builtin_fmaf(-89267.0f, cr, __builtin_fmaf(-43017.0f, cb, 62505.0f)) * (1.0f / 125000.0f);
+    const float fr = __builtin_amdgcn_fractf(qr), fb = __builtin_amdgcn_fractf(qb), fg = __builtin_amdgcn_fractf(qg);
+    tie = fr < 2.5e-4f || fb < 2.5e-4f || fg < 8e-5f;
+    r = __builtin_amdgcn_fmed3f(qr - fr, 0.0f, 255.0f);
+    b = __builtin_amdgcn_fmed3f(qb - fb, 0.0f, 255.0f);
+    g = __builtin_amdgcn_fmed3f(Y + (qg - fg), 0.0f, 255.0f);
+}
+
 constexpr float inv_c(int u, int x) { return scale_s(u) * cos_c(u, x); }  // fl32(s(u) * C[u][x]), :131,:142
 
 

@@ -384,8 +384,15 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
                 uint8_t rr, gg, bb;
                 const int c0 = (int)((yy[p >> 2] >> sh) & 0xffu), c1 = (int)((cbb[p >> 2] >> sh) & 0xffu),
                           c2 = (int)((crr[p >> 2] >> sh) & 0xffu);
-                if (mode.passthrough) { rr = (uint8_t)c0; gg = (uint8_t)c1; bb = (uint8_t)c2; }   // colour_mapping.cpp:28-37
-                else colour_inverse(c0, c1, c2, rr, gg, bb);
+                if (mode.passthrough) {   // colour_mapping.cpp:28-37
+                    rr = (uint8_t)c0; gg = (uint8_t)c1; bb = (uint8_t)c2;
+                } else {
+                    float fr, fg, fb;
+                    bool tie;
+                    colour_inverse_fast((float)c0, (float)c1, (float)c2, fr, fg, fb, tie);
+                    rr = (uint8_t)fr; gg = (uint8_t)fg; bb = (uint8_t)fb;
+                    if (__builtin_expect(__any(tie), 0)) colour_inverse(c0, c1, c2, rr, gg, bb);   // the literal formula
+                }
                 const uint8_t px3[3] = {rr, gg, bb};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -414,8 +421,15 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             const int Cb = lds_px[(1 * kMcusPerGroup + mm) * 64 + r * 8 + p];
             const int Cr = lds_px[(2 * kMcusPerGroup + mm) * 64 + r * 8 + p];
             uint8_t rr, gg, bb;
-            if (mode.passthrough) { rr = (uint8_t)Y; gg = (uint8_t)Cb; bb = (uint8_t)Cr; }
-            else colour_inverse(Y, Cb, Cr, rr, gg, bb);
+            if (mode.passthrough) {
+                rr = (uint8_t)Y; gg = (uint8_t)Cb; bb = (uint8_t)Cr;
+            } else {
+                float fr, fg, fb;
+                bool tie;
+                colour_inverse_fast((float)Y, (float)Cb, (float)Cr, fr, fg, fb, tie);
+                rr = (uint8_t)fr; gg = (uint8_t)fg; bb = (uint8_t)fb;
+                if (tie) colour_inverse(Y, Cb, Cr, rr, gg, bb);
+            }
             uint8_t* dst = img + ((size_t)y * width + x) * 3;
             dst[0] = rr; dst[1] = gg; dst[2] = bb;
         }
@@ -442,8 +456,13 @@ __global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, size_t n, u
 
 __global__ void ycbcr_to_rgb_kernel(const uint8_t* __restrict__ ycc, size_t n, uint8_t* __restrict__ rgb) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        uint8_t r, g, b;
-        colour_inverse(ycc[3 * i], ycc[3 * i + 1], ycc[3 * i + 2], r, g, b);
+        // the inverse kernel's two paths: exact arithmetic, literal double formula near rounding ties
+        const int Y = ycc[3 * i], Cb = ycc[3 * i + 1], Cr = ycc[3 * i + 2];
+        float fr, fg, fb;
+        bool tie;
+        colour_inverse_fast((float)Y, (float)Cb, (float)Cr, fr, fg, fb, tie);
+        uint8_t r = (uint8_t)fr, g = (uint8_t)fg, b = (uint8_t)fb;
+        if (tie) colour_inverse(Y, Cb, Cr, r, g, b);
         rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b;
     }
 }
