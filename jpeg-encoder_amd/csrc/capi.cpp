@@ -833,7 +833,7 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
 // kernels made of a file with a bad header is bounded and thrown away.
 static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_t* h_offsets, const uint64_t* h_sizes,
                               size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs, const char* what,
-                              uint8_t* d_planar_masks = nullptr, const std::function<void()>& follow_up = nullptr) {
+                              uint32_t* d_block_records = nullptr, const std::function<void()>& follow_up = nullptr) {
     int rc;
     const bool with_headers = skip == JEA_HEADER_BYTES;
     const size_t seg_bytes = 3 * n_images * sizeof(uint64_t);   // offsets | sizes | unstuffed bases
@@ -909,7 +909,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.grp_sum = (int4*)ctx->grp_sum.ptr;
     sc.grp_base = (int4*)ctx->grp_base.ptr;
     sc.changed = (uint32_t*)ctx->round_flags.ptr;
-    sc.out_masks = d_planar_masks;
+    sc.out_records = d_block_records;
     sc.mode = ctx->mode;
     sc.grp_pending = (uint32_t*)ctx->grp_pending.ptr;
     sc.sub_guess = (uint32_t*)ctx->sub_guess.ptr;
@@ -952,17 +952,17 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     const size_t mcus = mcus_of(width, height);
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
-    // the coefficients stay inside the library: chunk-planar layout with chunk masks
-    if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3))) return rc;
+    // the coefficients stay inside the library: block records and chunk planes
+    if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3 * sizeof(uint32_t)))) return rc;
     // The inverse transform is enqueued right behind the write pass, before anything is known about the
     // stream: a decode waits for the GPU once.  So when an error is reported, d_rgb holds garbage.
     const QuantTables qt = to_float_tables(lum_q, chr_q);
     auto inverse = [&]() {
         launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height, qt, d_rgb,
-                            (const uint8_t*)ctx->masks.ptr, ctx->mode);
+                            (const uint32_t*)ctx->masks.ptr, ctx->mode);
     };
     return run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,
-                              (int16_t*)ctx->coefs.ptr, "jea_decode_batch", (uint8_t*)ctx->masks.ptr, inverse);
+                              (int16_t*)ctx->coefs.ptr, "jea_decode_batch", (uint32_t*)ctx->masks.ptr, inverse);
 }
 
 int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t width, uint16_t height,

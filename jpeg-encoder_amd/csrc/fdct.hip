@@ -271,7 +271,7 @@ __device__ __forceinline__ void idct_cols(const float (&tmp)[8][8], uint8_t* __r
 
 template <bool kPlanar>
 __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_t* __restrict__ coefs,
-                                                                    const uint8_t* __restrict__ chunk_masks, int width,
+                                                                    const uint32_t* __restrict__ records, int width,
                                                                     int height, int blocks_w, uint32_t n_mcu,
                                                                     size_t image_bytes, QuantTables q,
                                                                     uint8_t* __restrict__ rgb, ComponentMode mode) {
@@ -310,14 +310,17 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
         // The transform is then run on the smallest triangle u + v <= D that holds them all.
         bool rest_nonzero;
         if (kPlanar) {
-            // Chunk-planar input: each thread fetches the chunks of its own block (the lanes of a wave
-            // are consecutive 16-byte elements of a plane) into its LDS slot; the masks say which
-            // chunks exist, and chunks beyond the first are not even copied when the whole wave has none.
+            // The decoder's layout: each thread fetches its block's record and the chunks that exist (the
+            // lanes of a wave are consecutive 16-byte elements of a plane) into its LDS slot; chunks
+            // beyond the first are not even looked at when the whole wave has none.
             const uint32_t mcu = g0 + (uint32_t)m;
-            const uint32_t mask = chunk_masks[((size_t)blockIdx.y * n_mcu + mcu) * 3 + channel];
+            const uint32_t rec = records[((size_t)blockIdx.y * n_mcu + mcu) * 3 + channel];
+            const uint32_t mask = (rec >> 16) & 0xffu;
             const uint4* plane = reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu + mcu;
             rest_nonzero = (mask >> 1) != 0;
-            *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[0])) = plane[0];
+            uint4 first = make_uint4(rec & 0xffffu, 0, 0, 0);   // DC alone
+            if (mask & 1u) first = plane[0];
+            *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[0])) = first;
             if (__ballot(rest_nonzero) != 0) {
 #pragma unroll
                 for (int c = 1; c < 8; ++c) {
@@ -489,13 +492,13 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
 }
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
-                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks, ComponentMode mode) {
+                         const QuantTables& q, uint8_t* d_rgb, const uint32_t* d_records, ComponentMode mode) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
-    if (d_chunk_masks != nullptr)
-        idct_dequant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_coefs, d_chunk_masks, width, height, bw, n_mcu,
+    if (d_records != nullptr)
+        idct_dequant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu,
                                                                 image_bytes, q, d_rgb, mode);
     else
         idct_dequant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_coefs, nullptr, width, height, bw, n_mcu,

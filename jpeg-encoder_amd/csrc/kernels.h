@@ -201,8 +201,8 @@ struct DecodeScratch {
     uint32_t* ctx_vals;             // ... and the start states remembered under them
     uint32_t ctx_slots;
     ComponentMode mode;
-    uint8_t* out_masks;      // null: coefficients go out as [block][64]; else they go out chunk-planar (as
-                             // launch_fdct_quant describes it) and this receives [n][mcus*3] chunk masks
+    uint32_t* out_records;   // null: coefficients go out as [block][64]; else they go out as block records
+                             // [n][mcus*3] plus chunk planes, see launch_idct_dequant
 };
 
 // What the decoder tells the host, in host memory that the GPU can write (hipHostMalloc).
@@ -233,9 +233,14 @@ hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const D
 void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
                            uint32_t header_bytes, uint8_t* d_out);
 
-// d_chunk_masks null: d_coefs is [image][mcu][channel][64]; else chunk-planar with these masks.
+// d_records null: d_coefs is [image][mcu][channel][64].  Else the decoder's own layout: one 32-bit record
+// per block-channel, [image][mcu*3 + channel] = DC value (low 16 bits) | chunk mask << 16, and the chunk
+// planes of launch_fdct_quant, in which only the chunks whose mask bit is set exist.  Mask bit c >= 1: chunk c
+// (zig-zag positions 8c..8c+7) has a non-zero coefficient; bit 0: one of positions 1..7 is non-zero (the
+// stored chunk 0 repeats the DC value).  A block without AC coefficients is its record and nothing else:
+// one 4-byte store for the decoder instead of a chunk and a mask byte.
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
-                         const QuantTables& q, uint8_t* d_rgb, const uint8_t* d_chunk_masks = nullptr,
+                         const QuantTables& q, uint8_t* d_rgb, const uint32_t* d_records = nullptr,
                          ComponentMode mode = ComponentMode{});
 
 // Per-block (component granularity) launchers, blocks.hip.
