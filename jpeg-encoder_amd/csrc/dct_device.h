@@ -8,6 +8,12 @@
 
 namespace jea {
 
+__device__ __forceinline__ float min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // colour_mapping.cpp:48-51: floor(in + 0.5), clamp to [0, 255]
 __device__ __forceinline__ double round_to_range(double v) {
     v = floor(v + 0.5);
@@ -132,12 +138,6 @@ __device__ __forceinline__ int quantise_fast(float o, float rq, float& margin) {
     return n;
 }
 
-__device__ __forceinline__ float min3(float a, float b, float c) {
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // Quantises the eight coefficients out[8v+u], v = 0..7, of one column u.
 __device__ __forceinline__ void quantise_col(const float (&o)[8], const float* __restrict__ qt,
                                              const float* __restrict__ rqt, int u, int* __restrict__ qv) {
@@ -166,22 +166,29 @@ __device__ __forceinline__ void colour_inverse(int Y, int Cb, int Cr, uint8_t& r
 //                                                              Y is an integer and may leave the floor)
 // wherever the reference's double arithmetic, whose error is some 1e-13, cannot land on the other side of
 // an integer, i.e. everywhere but at numerators that are multiples of M (ties).  Numerators are built by
-// exact FMAs with d*M added (0.125 for M = 1000; 5 for M = 125000, where the corner |cb|, |cr| ~ 128 passes
+// exact FMAs with d*M added (0.125 for M = 1000; 16 for M = 125000, where the corner |cb|, |cr| ~ 128 passes
 // 2^24 and may be off by one unit: that is 8e-6 of a quotient and counted in the margin), divided by a
 // multiply with RN(1/M) -- quotients up to 482 resp. 136 in magnitude, so within 5.8e-5 resp. 2.5e-5 of the
-// true (t / M) + d, both below d = 1.25e-4 resp. 4e-5 -- and flagged when fract(q) < 2d.  Unflagged,
-// floor(q) = floor(t / M).  Values still need the clamp to [0, 255] (:49-51).
+// true (t / M) + d, both well below d = 1.25e-4 resp. 1.28e-4 -- and flagged when fract(q) < 2.5e-4: every
+// tie has its fract(q) in [d - e, d + e], below that bound, and an unflagged quotient has
+// frac((t / M) + d) > 2.5e-4 - e > d, so that floor(q) = floor(t / M).  Values still need the clamp to
+// [0, 255] (:49-51); they are integers, so the conversion to bytes is exact.
 __device__ __forceinline__ void colour_inverse_fast(float Y, float Cb, float Cr, float& r, float& g, float& b, bool& tie) {
     const float cb = Cb - 128.0f, cr = Cr - 128.0f;
     const float y1000 = __builtin_fmaf(1000.0f, Y, 500.125f);
     const float qr = __builtin_fmaf(1402.0f, cr, y1000) * (1.0f / 1000.0f);
     const float qb = __builtin_fmaf(1772.0f, cb, y1000) * (1.0f / 1000.0f);
-    const float qg = __builtin_fmaf(-89267.0f, cr, __builtin_fmaf(-43017.0f, cb, 62505.0f)) * (1.0f / 125000.0f);
+    const float qg = __builtin_fmaf(-89267.0f, cr, __builtin_fmaf(-43017.0f, cb, 62516.0f)) * (1.0f / 125000.0f);
     const float fr = __builtin_amdgcn_fractf(qr), fb = __builtin_amdgcn_fractf(qb), fg = __builtin_amdgcn_fractf(qg);
-    tie = fr < 2.5e-4f || fb < 2.5e-4f || fg < 8e-5f;
+    tie = min3(fr, fb, fg) < 2.5e-4f;
     r = __builtin_amdgcn_fmed3f(qr - fr, 0.0f, 255.0f);
     b = __builtin_amdgcn_fmed3f(qb - fb, 0.0f, 255.0f);
     g = __builtin_amdgcn_fmed3f(Y + (qg - fg), 0.0f, 255.0f);
+}
+
+// byte `index` (0..3) of `word` replaced by the value, an integer in [0, 255] held as a float
+__device__ __forceinline__ uint32_t insert_byte(float value, uint32_t index, uint32_t word) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(value, index, word);
 }
 
 constexpr float inv_c(int u, int x) { return scale_s(u) * cos_c(u, x); }  // fl32(s(u) * C[u][x]), :131,:142

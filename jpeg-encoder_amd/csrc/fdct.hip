@@ -384,23 +384,24 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int sh = 8 * (p & 3);
-                uint8_t rr, gg, bb;
                 const int c0 = (int)((yy[p >> 2] >> sh) & 0xffu), c1 = (int)((cbb[p >> 2] >> sh) & 0xffu),
                           c2 = (int)((crr[p >> 2] >> sh) & 0xffu);
+                float px3[3];
                 if (mode.passthrough) {   // colour_mapping.cpp:28-37
-                    rr = (uint8_t)c0; gg = (uint8_t)c1; bb = (uint8_t)c2;
+                    px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
                 } else {
-                    float fr, fg, fb;
                     bool tie;
-                    colour_inverse_fast((float)c0, (float)c1, (float)c2, fr, fg, fb, tie);
-                    rr = (uint8_t)fr; gg = (uint8_t)fg; bb = (uint8_t)fb;
-                    if (__builtin_expect(__any(tie), 0)) colour_inverse(c0, c1, c2, rr, gg, bb);   // the literal formula
+                    colour_inverse_fast((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);
+                    if (__builtin_expect(__any(tie), 0)) {   // the literal formula
+                        uint8_t rr, gg, bb;
+                        colour_inverse(c0, c1, c2, rr, gg, bb);
+                        px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
+                    }
                 }
-                const uint8_t px3[3] = {rr, gg, bb};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int byte = 3 * p + c;
-                    out[byte >> 2] |= (uint32_t)px3[c] << (8 * (byte & 3));
+                    out[byte >> 2] = insert_byte(px3[c], byte & 3, out[byte >> 2]);
                 }
             }
             uint2* dst = reinterpret_cast<uint2*>(img + ((size_t)y * width + (size_t)bx * 8) * 3);
