@@ -301,6 +301,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     const bool valid = (uint32_t)m < mcus_here;
     const float* qt = mode.is_lum(channel) ? q.lum : q.chr;
     float tmp[8][8];
+    float dc_only = 0.0f;
     int diag = 7;
     if (valid) {
         const uint8_t* chunk[8];
@@ -346,8 +347,15 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             // diagonals u + v = 0,1 | 1,2 | 2,2 | 3,3
             const uint4 c0 = *reinterpret_cast<const uint4*>(chunk[0]);
             diag = __ballot(c0.w != 0) != 0 ? 3 : ((__ballot((c0.y | c0.z) != 0) != 0) ? 2 : 1);
+            if (diag == 1 && __ballot((c0.x >> 16) != 0) == 0) {
+                // DC alone in all 64 blocks: every sample of a block is the same value,
+                // s(0)C[0][y] * (s(0)C[0][x] * deq[0]) with C[0][.] = 1, clamped and truncated as in idct_cols
+                diag = 0;
+                dc_only = inv_c(0, 0) * (inv_c(0, 0) * ((float)(int)(int16_t)(c0.x & 0xffffu) * qt[0]));
+            }
         }
         switch (diag) {
+            case 0: break;
             case 1: idct_rows<1>(chunk, qt, tmp); break;
             case 2: idct_rows<2>(chunk, qt, tmp); break;
             case 3: idct_rows<3>(chunk, qt, tmp); break;
@@ -358,6 +366,13 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     if (valid) {
         uint8_t* dst = lds_px + (channel * kMcusPerGroup + m) * 64;
         switch (diag) {
+            case 0: {
+                const uint32_t o = (uint32_t)((int)__builtin_amdgcn_fmed3f(dc_only, -128.0f, 127.0f) + 128);
+                const uint32_t four = o * 0x01010101u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) reinterpret_cast<uint4*>(dst)[i] = make_uint4(four, four, four, four);
+                break;
+            }
             case 1: idct_cols<1>(tmp, dst); break;
             case 2: idct_cols<2>(tmp, dst); break;
             case 3: idct_cols<3>(tmp, dst); break;
