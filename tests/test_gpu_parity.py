@@ -326,6 +326,24 @@ def test_decode_periodic_streams(ctx, po, jea):
         assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(jpeg, w, h, quality)), (w, h, kind)
 
 
+def test_decode_flat_regions_next_to_detail(ctx, po, jea):
+    """Blocks that are a DC value alone take shortcuts in the decoder (a record instead of a chunk, samples
+    filled without a transform where a whole wave is flat): flat areas of extreme and ordinary colours,
+    wider than the 64 MCUs of a wave and narrower, with noise between them."""
+    w, h = 1280, 200
+    rng = np.random.RandomState(3)
+    rgb = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    rgb[:64] = (255, 0, 0)
+    rgb[64:96, :700] = (0, 0, 0)
+    rgb[64:96, 700:] = (255, 255, 255)
+    rgb[96:136, 100:420] = (12, 200, 77)
+    rgb[136:168, ::2] = 128            # not flat at all
+    for quality in (10, 75, 100):
+        lum, chrom = jea.binding.quant_tables(quality)
+        jpeg = po.encode(rgb, quality)
+        assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(jpeg, w, h, quality)), quality
+
+
 def test_decode_damaged_streams_agree_with_oracle(ctx, po, jea):
     """A damaged scan either fails in both decoders or decodes to the same picture in both
     (entropy_encoder.cpp:775-777,825-827 and the bounds of :122-144; encoder.cpp:63-65)."""
