@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="contexts (HIP streams) the steps alternate over; independent images overlap")
     ap.add_argument("--mode", type=int, default=0, help="0 smooth gradients + noise, 1 uniform noise")
+    ap.add_argument("--ramp-seconds", type=float, default=0.1,
+                    help="untimed steps before the warm-up, for the GPU clocks (0 for counter-collection runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=10, help="images of the CPU sample")
     args = ap.parse_args()
@@ -127,7 +129,7 @@ def main():
     # The parity gate above left the GPU idle while the CPU encoded; its clocks take some milliseconds of
     # load to come back up.  Untimed steps until 0.1 s has passed, then the W warm-up steps as asked.
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.1:
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
         for _ in range(50):
             step()
         sync_all()

@@ -18,15 +18,23 @@ def per_kernel(directory, counter):
             if r["Counter_Name"] != counter:
                 continue
             m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
-            acc[m.group(1) if m else r["Kernel_Name"][:40]].append(float(r["Counter_Value"]))
-    return acc
+            name = m.group(1) if m else r["Kernel_Name"][:40]
+            acc[(name, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    # a kernel that was launched with several grid sizes (the bench also launches the forward kernel on
+    # four images at once) is reported for the size it was launched with most often
+    best = {}
+    for (name, grid), values in acc.items():
+        if name not in best or len(values) > len(best[name][1]):
+            best[name] = (grid, values)
+    return {name: values for name, (grid, values) in best.items()}
 
 
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 20 "
-                   "--warmup 2 --no-cpu-baseline --streams 1`; FETCH_SIZE doubled for gfx950 (128-byte read requests are "
-                   "counted as 64 bytes), WRITE_SIZE taken as is; both in KB; means over the launches of each kernel",
+                   "--warmup 2 --ramp-seconds 0 --no-cpu-baseline --streams 1`; FETCH_SIZE doubled for gfx950 (128-byte read requests are "
+                   "counted as 64 bytes), WRITE_SIZE taken as is; both in KB; means over the launches of each kernel "
+                   "with its most frequent grid size (the single-image launches)",
            "workload": sys.argv[3], "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else 0.0
