@@ -35,6 +35,20 @@ HBM_PEAK_GBS = 8000.0
 K1_BYTES_PER_PIXEL = 9.0  # 3 B RGB read + 3 x int16 coefficient write
 
 
+def photo_like_image(width, height, seed):
+    """Noise with a 1/f amplitude spectrum per channel, correlated across channels: the statistics of a
+    photograph rather than of a gradient (mode 0) or of white noise (mode 1)."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    fy, fx = np.fft.fftfreq(height)[:, None], np.fft.fftfreq(width)[None, :]
+    amp = 1.0 / np.maximum(np.hypot(fx, fy), 1.0 / max(width, height)) ** 1.1
+    shaped = lambda: np.fft.ifft2(np.fft.fft2(rng.standard_normal((height, width))) * amp).real
+    base = shaped()
+    chans = [base + 0.3 * shaped() for _ in range(3)]
+    return np.stack([np.clip(128 + 48 * c / c.std(), 0, 255) for c in chans], axis=-1).astype(np.uint8)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,7 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per step")
     ap.add_argument("--streams", type=int, default=3,
                     help="contexts (HIP streams) the steps alternate over; independent images overlap")
-    ap.add_argument("--mode", type=int, default=0, help="0 smooth gradients + noise, 1 uniform noise")
+    ap.add_argument("--mode", type=int, default=0,
+                    help="0 smooth gradients + noise (the default workload), 1 uniform noise, 2 photo-like 1/f noise")
     ap.add_argument("--ramp-seconds", type=float, default=0.1,
                     help="untimed steps before the warm-up, for the GPU clocks (0 for counter-collection runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,7 +100,8 @@ def main():
     # synthetic input, resident in HBM before the timed region; every rank gets its own images
     import pyoracle as po  # generator + checker only; nothing timed on the GPU side calls it
 
-    imgs = np.stack([po.gen_image(W, H, args.mode, 1234 + rank * args.batch + i) for i in range(args.batch)])
+    gen = (lambda seed: photo_like_image(W, H, seed)) if args.mode == 2 else (lambda seed: po.gen_image(W, H, args.mode, seed))
+    imgs = np.stack([gen(1234 + rank * args.batch + i) for i in range(args.batch)])
     d_rgb = ctx.to_device(imgs.reshape(-1))
     cap = args.batch * (3 * W * H // 2 + (1 << 20)) if args.mode == 0 else args.batch * binding.max_jpeg_bytes(W, H)
     # every context has its own output and bookkeeping buffers; the input images are shared (read only)
@@ -222,7 +238,7 @@ def main():
             "metric": "encode MPix/s (q=75)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic %s RGB8 (mt19937 seed 1234+), resident in HBM" % ("smooth" if args.mode == 0 else "noise"),
+            "data": "synthetic %s RGB8 (seed 1234+), resident in HBM" % ("smooth", "noise", "photo-like")[args.mode],
             "config": {"workload": "single 3840x2160 RGB image encode at q=75 per step" if args.batch == 1 else
                        "%d x 3840x2160 RGB images encoded at q=75 per step" % args.batch,
                        "images_per_step": args.batch, "width": W, "height": H, "quality": QUALITY,

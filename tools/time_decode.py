@@ -11,13 +11,8 @@ w, h, q, mode, n = (int(a) for a in sys.argv[1:6])
 ctx = jea.Context(0)
 lum, chrom = jea.binding.quant_tables(q)
 if mode == 2:
-    # photo-like statistics: noise with a 1/f amplitude spectrum per channel, correlated across channels
-    rng = np.random.default_rng(1234)
-    fy, fx = np.fft.fftfreq(h)[:, None], np.fft.fftfreq(w)[None, :]
-    amp = 1.0 / np.maximum(np.hypot(fx, fy), 1.0 / max(w, h)) ** 1.1
-    base = np.fft.ifft2(np.fft.fft2(rng.standard_normal((h, w))) * amp).real
-    chans = [base + 0.3 * np.fft.ifft2(np.fft.fft2(rng.standard_normal((h, w))) * amp).real for _ in range(3)]
-    rgb = np.stack([np.clip(128 + 48 * c / c.std(), 0, 255) for c in chans], axis=-1).astype(np.uint8)
+    from bench import photo_like_image
+    rgb = photo_like_image(w, h, 1234)
 else:
     rgb = po.gen_image(w, h, mode, 1234)
 d_rgb = ctx.to_device(np.tile(rgb.reshape(-1), n))
