@@ -44,10 +44,10 @@ struct jea_ctx {
     ComponentMode mode;   // jea_set_colour_mapper
     // scratch, grown on demand and kept
     DeviceBuffer coefs, masks, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
-    DeviceBuffer stage_in, stage_out, seg_offsets, seg_sizes, out_offsets, out_sizes;
+    DeviceBuffer stage_in, stage_out, seg_offsets, out_offsets, out_sizes;
     DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
     // parallel decode
-    DeviceBuffer seg_ubase, ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
+    DeviceBuffer ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
         round_flags, grp_pending, sub_guess, first_bad, ctx_keys, ctx_vals;
     void* pinned = nullptr;   // host memory the GPU reads and writes: decode bookkeeping
     size_t pinned_bytes = 0;
@@ -356,8 +356,8 @@ void jea_destroy(jea_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (DeviceBuffer* b : {&ctx->coefs, &ctx->masks, &ctx->len16, &ctx->slots, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
                             &ctx->tile_ffbase, &ctx->img_words, &ctx->unstuffed, &ctx->stage_in, &ctx->stage_out,
-                            &ctx->seg_offsets, &ctx->seg_sizes, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small,
-                            &ctx->seg_ubase, &ctx->ustream, &ctx->chunk_drops, &ctx->chunk_base, &ctx->img_drops,
+                            &ctx->seg_offsets, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small,
+                            &ctx->ustream, &ctx->chunk_drops, &ctx->chunk_base, &ctx->img_drops,
                             &ctx->sub_end, &ctx->sub_used, &ctx->sub_info, &ctx->grp_sum, &ctx->grp_base,
                             &ctx->round_flags, &ctx->grp_pending, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
                             &ctx->ctx_vals})
