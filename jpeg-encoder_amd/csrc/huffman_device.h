@@ -73,6 +73,7 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
         sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
     }
     uint32_t run = 0;
+    uint32_t largest = 0;   // largest AC magnitude: the range is checked once, after the walk
     // Coefficients are walked in groups of eight (one 16-byte load); a group that is
     // all zero only extends the run.  High zig-zag positions are zero in most
     // blocks, and a wave skips the group body when none of its lanes needs it.
@@ -94,10 +95,12 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
                     run -= 16;
                 }
                 const uint32_t amp = (uint32_t)(v < 0 ? -v : v);
+                largest = amp > largest ? amp : largest;
                 uint32_t s = bit_width(amp);
-                if (s > 10) { ok = false; s = 10; }
+                s = s < 10u ? s : 10u;           // keeps the table index and the bit count in range when the value is not
                 const uint32_t e = ac_tab[(run << 4) | s];
-                const uint32_t extra = (v > 0 ? amp : ~amp) & ((1u << s) - 1u);
+                // the low s bits of v (v > 0) or of v - 1 (v < 0), entropy_encoder.cpp:745-765
+                const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)(v + (v >> 31)), 0u, s);
                 sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
                 run = 0;
             } else {
@@ -105,6 +108,7 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
             }
         }
     }
+    if (largest > 1023u) ok = false;
     if (run > 0) {  // zz[63] == 0: trailing zeros (and their ZRLs) collapse into EOB
         const uint32_t e = ac_tab[0x00];
         sink.put(e & 0xffffu, e >> 16);
