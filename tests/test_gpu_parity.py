@@ -509,3 +509,40 @@ def test_striped_encode_all_ff_boundaries(ctx, po, jea):
         finally:
             for c in ctxs:
                 c.close()
+
+
+def test_random_shapes_qualities_and_contents(ctx, po, jea):
+    """A randomised sweep (fixed seed): odd shapes, every quality range, smooth, noisy, flat-with-patches,
+    low-amplitude and saturated pictures, through the whole encode and the whole decode.
+    tools/stress_parity.py runs the same sweep with thousands of cases."""
+    rng = np.random.RandomState(11)
+
+    def content(w, h, kind):
+        if kind < 2:
+            return po.gen_image(w, h, kind, int(rng.randint(1 << 30)))
+        if kind == 2:
+            img = np.empty((h, w, 3), np.uint8)
+            img[:] = rng.randint(0, 256, 3)
+            for _ in range(rng.randint(1, 6)):
+                y0, x0 = rng.randint(0, h), rng.randint(0, w)
+                y1, x1 = y0 + rng.randint(1, h + 1), x0 + rng.randint(1, w + 1)
+                if rng.randint(2):
+                    img[y0:y1, x0:x1] = rng.randint(0, 256, 3)
+                else:
+                    img[y0:y1, x0:x1] = rng.randint(0, 256, img[y0:y1, x0:x1].shape)
+            return img
+        if kind == 3:
+            return np.clip(rng.randint(0, 256, 3) + rng.randint(-6, 7, (h, w, 3)), 0, 255).astype(np.uint8)
+        return (rng.randint(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+
+    for i in range(120):
+        w, h = int(rng.randint(1, 700)), int(rng.randint(1, 400))
+        if rng.randint(4) == 0:
+            w, h = 8 * (w // 8 + 1), 8 * (h // 8 + 1)
+        quality = int(rng.choice([1, 5, 10, 25, 50, 75, 90, 95, 100]))
+        kind = int(rng.randint(5))
+        rgb = np.ascontiguousarray(content(w, h, kind))
+        lum, chrom = jea.binding.quant_tables(quality)
+        want = po.encode(rgb, quality)
+        assert bytes(ctx.encode_host(rgb, lum, chrom)) == want, (i, w, h, quality, kind)
+        assert np.array_equal(ctx.decode_host(want, w, h, lum, chrom), po.decode(want, w, h, quality)), (i, w, h, quality, kind)
