@@ -79,15 +79,14 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
                                                                  ComponentMode mode) {
     __shared__ HuffLds h;
     __shared__ uint32_t wsum[4];
-    load_huff(h, huff);
-    __syncthreads();
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
-    uint32_t bits = 0;
-    if (threadIdx.x < kTileBlocks && b < nbc) {
-        BlockRegs blk;
-        const int ch = (int)(b % 3u);
-        int prev_dc;
+    const bool has_block = threadIdx.x < kTileBlocks && b < nbc;
+    // the block's own loads go out first, so that they are under way while the tables are copied
+    BlockRegs blk;
+    const int ch = (int)(b % 3u);
+    int prev_dc = 0;
+    if (has_block) {
         // previous DC: same channel, previous MCU; the chain starts at 0 (encoder.cpp:20) or, in a
         // stripe, at the last MCU of the stripe above
         if (kPlanar) {
@@ -100,6 +99,11 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
             load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
             prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
         }
+    }
+    load_huff(h, huff);
+    __syncthreads();
+    uint32_t bits = 0;
+    if (has_block) {
         bool ok;
         const int cls = mode.is_lum((uint32_t)ch) ? 0 : 1;   // Huffman table class (encoder.cpp:25)
         if (kEmit) {
@@ -226,36 +230,29 @@ __global__ __launch_bounds__(1024) void scan_images_kernel(uint32_t n_images, co
     }
 }
 
-// Sum of arr[0..count) over a 256-thread workgroup (every thread gets the result).
-// Used instead of a separate scan launch when one image has few tiles: each
-// workgroup adds up the totals of the tiles before it.
-__device__ __forceinline__ uint64_t block_sum_256(const uint32_t* __restrict__ arr, uint32_t count, uint64_t* lds4) {
+// Single images with few tiles skip the scan launches: each workgroup adds up the totals of the
+// tiles before it.  The loads are issued first thing in the kernel (fold_partial) and reduced where the
+// sum is needed (fold_reduce), so that their latency hides behind the kernel's other loads.
+__device__ __forceinline__ uint64_t fold_partial(const uint32_t* __restrict__ arr, uint32_t count) {
     uint64_t v = 0;
     for (uint32_t i = threadIdx.x; i < count; i += kEntThreads) v += arr[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const uint64_t total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-    __syncthreads();
-    return total;
+    return v;
 }
-
-// Bit range [base_bits, end_bits) of a tile in its image's stream: from the
-// scanned tile bases, or (kFold, single image) by summing the tile totals.
-template <bool kFold>
-__device__ __forceinline__ void tile_bit_range(uint32_t tile, uint32_t n_tiles, const uint32_t* __restrict__ tile_bits,
-                                               const uint64_t* __restrict__ tile_base,
-                                               const uint64_t* __restrict__ img_bits, uint32_t img, uint64_t* lds4,
-                                               uint64_t& base_bits, uint64_t& end_bits) {
-    if (kFold) {
-        base_bits = block_sum_256(tile_bits, tile, lds4);
-        end_bits = base_bits + tile_bits[tile];
-    } else {
-        const uint64_t* tb = tile_base + (size_t)img * n_tiles;
-        base_bits = tb[tile];
-        end_bits = (tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1];
+// Sums a and b over the 256 threads of the workgroup (every thread gets both results).
+__device__ __forceinline__ void fold_reduce(uint64_t& a, uint64_t& b, uint64_t* lds8) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d);
+        b += __shfl_xor(b, d);
     }
+    if ((threadIdx.x & 63) == 0) {
+        lds8[threadIdx.x >> 6] = a;
+        lds8[4 + (threadIdx.x >> 6)] = b;
+    }
+    __syncthreads();
+    a = lds8[0] + lds8[1] + lds8[2] + lds8[3];
+    b = lds8[4] + lds8[5] + lds8[6] + lds8[7];
+    __syncthreads();
 }
 
 template <bool kFold>
@@ -272,10 +269,11 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
                                                            int32_t* __restrict__ status, StripeInfo st) {
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4];
-    __shared__ uint64_t lsum[4];
+    __shared__ uint64_t lsum[8];
     __shared__ uint32_t ff_count;
-    if (*status != 0) return;
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
+    const int32_t status_now = *status;                       // looked at after the other loads are under way
+    uint64_t before = kFold ? fold_partial(tile_bits, tile) : 0, unused = 0;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     // 252 own block-channels + the first MCU of the next tile (threads 252..254)
     const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
@@ -283,12 +281,21 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     // successor's first blocks with the 32 head bits it was given
     const bool head_thread = st.has_next && tile + 1 == n_tiles && threadIdx.x == kTileBlocks;
     const uint32_t my_len = has_block ? len16[(size_t)img * nbc + b] : (head_thread ? 32u : 0u);
+    if (status_now != 0) return;
     if (threadIdx.x == 0) ff_count = 0;
     uint32_t tile_total;
     const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);  // has barriers
 
     uint64_t base_bits, end_bits;
-    tile_bit_range<kFold>(tile, n_tiles, tile_bits, tile_base, img_bits, img, lsum, base_bits, end_bits);
+    if (kFold) {
+        fold_reduce(before, unused, lsum);
+        base_bits = before;
+        end_bits = base_bits + tile_bits[tile];
+    } else {
+        const uint64_t* tb = tile_base + (size_t)img * n_tiles;
+        base_bits = tb[tile];
+        end_bits = (tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1];
+    }
     base_bits += st.bit_base;  // image-stream coordinates
     end_bits += st.bit_base;
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1)
@@ -366,17 +373,28 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
                                                             uint8_t* __restrict__ out, uint64_t out_capacity,
                                                             int32_t* __restrict__ status, StripeInfo st) {
     __shared__ uint32_t wsum[4];
-    __shared__ uint64_t lsum[4];
-    if (*status != 0) return;
+    __shared__ uint64_t lsum[8];
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
+    const int32_t status_now = *status;
+    uint64_t bits_before = kFold ? fold_partial(tile_bits, tile) : 0;
+    uint64_t ff_fold = kFold ? fold_partial(tile_ff, tile) : 0;
+    if (status_now != 0) return;
     uint64_t base_bits, end_bits;
-    tile_bit_range<kFold>(tile, n_tiles, tile_bits, tile_base, img_bits, img, lsum, base_bits, end_bits);
+    if (kFold) {
+        fold_reduce(bits_before, ff_fold, lsum);
+        base_bits = bits_before;
+        end_bits = base_bits + tile_bits[tile];
+    } else {
+        const uint64_t* tb = tile_base + (size_t)img * n_tiles;
+        base_bits = tb[tile];
+        end_bits = (tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1];
+    }
     base_bits += st.bit_base;
     end_bits += st.bit_base;
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;
     uint64_t ff_before, file_offset;
     if (kFold) {
-        ff_before = block_sum_256(tile_ff, tile, lsum);
+        ff_before = ff_fold;
         file_offset = 0;
         // the tile's last output byte (and, for the last tile, the EOI) must fit
         const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
