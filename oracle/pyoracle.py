@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libjpeg_oracle.so")
 REF_BITSTREAM_PATH = os.path.join(HERE, "_ref", "libref_bitstream.so")
-SURVEY_FNV_BASIS = 0x14650FB0739D0383
+RECORDED_FNV_BASIS = 0x14650FB0739D0383   # the basis the recorded reference hashes (tests/golden) were made with
 STD_FNV_BASIS = 0xCBF29CE484222325
 HEADER_BYTES = 607
 
@@ -70,7 +70,7 @@ def _p(a):
     return a.ctypes.data
 
 
-def fnv(data, basis=SURVEY_FNV_BASIS):
+def fnv(data, basis=RECORDED_FNV_BASIS):
     a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data)
     return "%016x" % LIB.jo_fnv1a64(_p(a), a.size, basis)
 
