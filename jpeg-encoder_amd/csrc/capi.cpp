@@ -917,7 +917,6 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.ctx_keys = (unsigned long long*)ctx->ctx_keys.ptr;
     sc.ctx_vals = (uint32_t*)ctx->ctx_vals.ptr;
     sc.ctx_slots = kContextSlots;
-    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
                                        ctx->d_status, follow_up, report));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));

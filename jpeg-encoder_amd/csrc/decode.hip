@@ -52,6 +52,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr uint32_t kChunkBytes = 4096;            // raw bytes per workgroup of the unstuffing passes
+constexpr uint32_t kFoldChunks = 4096;            // streams of up to this many chunks skip the scan launch
 constexpr uint32_t kNoState = 0xffffffffu;
 // Sub-sequence sizes in 32-bit words (template parameter W below).  Short ones give small streams
 // enough threads to fill the GPU; long ones keep the per-sub-sequence bookkeeping of big streams small.
@@ -119,9 +120,14 @@ __global__ __launch_bounds__(kThreads) void unstuff_count_kernel(const uint8_t* 
                                                                  const uint64_t* __restrict__ offsets,
                                                                  const uint64_t* __restrict__ sizes,
                                                                  uint32_t n_chunks,
-                                                                 uint32_t* __restrict__ chunk_drops) {
+                                                                 uint32_t* __restrict__ chunk_drops,
+                                                                 uint32_t* __restrict__ round_flags,
+                                                                 int32_t* __restrict__ status) {
     __shared__ uint32_t wsum[4];
     const uint32_t chunk = blockIdx.x, img = blockIdx.y;
+    // the decoder's first kernel also clears what the later ones report into
+    if (chunk == 0 && img == 0 && threadIdx.x < 4) round_flags[threadIdx.x] = 0;
+    if (chunk == 0 && img == 0 && threadIdx.x == 4) *status = 0;
     const uint64_t len = sizes[img];
     const uint64_t j0 = (uint64_t)chunk * kChunkBytes + 16u * threadIdx.x;
     uint32_t n = 0;
@@ -136,19 +142,41 @@ __global__ __launch_bounds__(kThreads) void unstuff_count_kernel(const uint8_t* 
     if (threadIdx.x == 0) chunk_drops[(size_t)img * n_chunks + chunk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// kFold (streams of few chunks): no scan launch in between; every workgroup adds up the drop counts of
+// the chunks before it, and the one with the stream's last chunk also leaves the image's total.
+template <bool kFold>
 __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t* __restrict__ scan,
                                                                    const uint64_t* __restrict__ offsets,
                                                                    const uint64_t* __restrict__ sizes,
                                                                    uint32_t n_chunks,
+                                                                   const uint32_t* __restrict__ chunk_drops,
                                                                    const uint64_t* __restrict__ chunk_base,
+                                                                   uint64_t* __restrict__ img_drops,
                                                                    const uint64_t* __restrict__ ubase,
                                                                    uint8_t* __restrict__ ustream) {
     __shared__ uint8_t kept[kChunkBytes];
     __shared__ uint32_t wsum[4];
+    __shared__ uint64_t fold4[4];
     const uint32_t chunk = blockIdx.x, img = blockIdx.y;
     const uint64_t len = sizes[img];
     const uint64_t c0 = (uint64_t)chunk * kChunkBytes;
-    if (c0 >= len) return;
+    if (c0 >= len) {
+        if (kFold && chunk == 0 && threadIdx.x == 0) img_drops[img] = 0;   // an empty stream
+        return;
+    }
+    uint64_t drops_before = 0;
+    if (kFold) {
+        for (uint32_t i = threadIdx.x; i < chunk; i += kThreads) drops_before += chunk_drops[(size_t)img * n_chunks + i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) drops_before += __shfl_xor(drops_before, d);
+        if ((threadIdx.x & 63) == 0) fold4[threadIdx.x >> 6] = drops_before;
+        __syncthreads();
+        drops_before = fold4[0] + fold4[1] + fold4[2] + fold4[3];
+        if (c0 + kChunkBytes >= len && threadIdx.x == 0)
+            img_drops[img] = drops_before + chunk_drops[(size_t)img * n_chunks + chunk];
+    } else {
+        drops_before = chunk_base[(size_t)img * n_chunks + chunk];
+    }
     const uint64_t j0 = c0 + 16u * threadIdx.x;
     uint8_t bytes[16];
     uint32_t mask = 0, valid = 0;
@@ -175,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
     __syncthreads();
     const uint32_t in_chunk = (uint32_t)((len - c0 < kChunkBytes) ? len - c0 : kChunkBytes);
     const uint32_t n_kept = in_chunk - total_drops;
-    uint8_t* dst = ustream + ubase[img] + c0 - chunk_base[(size_t)img * n_chunks + chunk];
+    uint8_t* dst = ustream + ubase[img] + c0 - drops_before;
     for (uint32_t i = threadIdx.x; i < n_kept; i += kThreads) dst[i] = kept[i];
 }
 
@@ -732,20 +760,37 @@ __global__ __launch_bounds__(kThreads) void context_kernel(const uint8_t* __rest
 // One workgroup per image: exclusive scan of the group sums; an image whose
 // stream holds fewer blocks than the picture needs is a stream error (the serial
 // decoder would run off the end of the file).
+//
+// With `unsettled` given it also does what one more synchronisation round would find out: whether
+// every workgroup's first sub-sequence was decoded from the end state of the sub-sequence before it
+// and no workgroup ran out of repair steps.  If so the fixed point is proven; if not the flag is set.
 __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __restrict__ grp_sum, uint32_t n_groups,
                                                                uint32_t total_blocks, int4* __restrict__ grp_base,
-                                                               int32_t* __restrict__ status) {
+                                                               int32_t* __restrict__ status,
+                                                               const uint64_t* __restrict__ sizes,
+                                                               const uint64_t* __restrict__ img_drops,
+                                                               uint32_t sub_bits, const uint32_t* __restrict__ sub_end,
+                                                               const uint32_t* __restrict__ sub_used,
+                                                               const uint32_t* __restrict__ grp_pending,
+                                                               uint32_t* __restrict__ unsettled) {
     __shared__ Sums lds4[4];
     __shared__ Sums carry_s;
     const uint32_t img = blockIdx.x;
     if (threadIdx.x == 0) carry_s = Sums{0, 0, 0, 0};
     __syncthreads();
+    const uint64_t total_bits = unsettled != nullptr ? 8 * (sizes[img] - img_drops[img]) : 0;
+    bool open_end = false;
     for (uint32_t g0 = 0; g0 < n_groups; g0 += kThreads) {
         const uint32_t g = g0 + threadIdx.x;
         Sums v{0, 0, 0, 0};
         if (g < n_groups) {
             const int4 s = grp_sum[(size_t)img * n_groups + g];
             v = Sums{s.x, s.y, s.z, s.w};
+            if (unsettled != nullptr && (uint64_t)g * kOwned * sub_bits < total_bits) {
+                const size_t first = ((size_t)img * n_groups + g) * kOwned;
+                const uint32_t entry = g > 0 ? sub_end[first - 1] : 0u;   // the stream starts in state 0
+                open_end = open_end || entry != sub_used[first] || grp_pending[(size_t)img * n_groups + g] != 0;
+            }
         }
         Sums total;
         const Sums excl = block_exclusive_scan(v, lds4, total);
@@ -755,6 +800,7 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
         if (threadIdx.x == 0) carry_s = carry_s + total;
         __syncthreads();
     }
+    if (open_end) atomicOr(unsettled, 1u);
     if (threadIdx.x == 0 && (uint32_t)carry_s.nb < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
 }
 
@@ -918,9 +964,10 @@ struct DecodeRun {
                                                          sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
                                                          sc.first_bad, sc.mode.lum_mask, flag);
     }
-    void scan_and_write() const {
+    void scan_and_write(uint32_t* check = nullptr) const {
         scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
-                                                           d_status);
+                                                           d_status, d_sizes, sc.img_drops, 32 * W, sc.sub_end,
+                                                           sc.sub_used, sc.grp_pending, check);
         if (sc.out_records != nullptr)
             decode_write_kernel<W, true><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
                                                                     p.n_groups, p.total_blocks, d_tables, sc.sub_used,
@@ -933,16 +980,15 @@ struct DecodeRun {
                                                                      sc.mode.lum_mask, d_status);
     }
 
-    // Three rounds up front: the first decodes everything, the second repairs the starts of the
-    // workgroups, the third normally finds nothing to do -- which is the proof of the fixed point.
-    // The write pass and whatever consumes the coefficients follow at once; whether the third round was
-    // indeed idle is reported together with the status, so the usual decode never waits for the GPU
-    // in the middle.
+    // Two rounds up front: the first decodes everything, the second repairs the starts of the
+    // workgroups.  The scan then checks what a third round would: that nothing is left to repair --
+    // which is the proof of the fixed point.  The write pass and whatever consumes the coefficients
+    // follow at once; the outcome of the check is reported together with the status, so the usual
+    // decode never waits for the GPU in the middle.
     hipError_t first_pass(const std::function<void()>& follow_up, DecodeReport* report) const {
         sync_round(1, sc.changed + 0, false);
         sync_round(0, sc.changed + 1, false);
-        sync_round(0, sc.changed + 2, false);
-        scan_and_write();
+        scan_and_write(sc.changed + 2);
         if (follow_up) follow_up();
         report_kernel<<<1, 1, 0, s>>>(sc.changed + 2, d_status, report);
         return hipGetLastError();
@@ -992,11 +1038,17 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
                                  const std::function<void()>& follow_up, DecodeReport* report) {
     hipError_t e;
     const dim3 cgrid(p.n_chunks, p.n_images);
-    unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops);
-    scan_chunks_kernel<<<p.n_images, 1024, 0, s>>>(sc.chunk_drops, p.n_chunks, sc.chunk_base, sc.img_drops);
-    unstuff_compact_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_base, sc.ubase,
-                                                      sc.ustream);
-    if ((e = hipMemsetAsync(sc.changed, 0, 4 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops, sc.changed,
+                                                    d_status);
+    if (p.n_chunks <= kFoldChunks) {
+        unstuff_compact_kernel<true><<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops,
+                                                                nullptr, sc.img_drops, sc.ubase, sc.ustream);
+    } else {
+        scan_chunks_kernel<<<p.n_images, 1024, 0, s>>>(sc.chunk_drops, p.n_chunks, sc.chunk_base, sc.img_drops);
+        unstuff_compact_kernel<false><<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops,
+                                                                 sc.chunk_base, sc.img_drops, sc.ubase, sc.ustream);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     switch (p.sub_words) {
         case kSubWordsSmall:
             return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);

@@ -214,7 +214,7 @@ struct DecodeReport {
 // Enqueues the whole decode -- unstuffing, three synchronisation rounds, scan and write pass -- then
 // `follow_up` (work that consumes the coefficients; may be empty), then a copy of the outcome to
 // *report, and returns without waiting.  Every block of d_coefs is written (chunk-planar: chunk 0 and
-// the non-zero chunks); errors go to *d_status.  After the stream has been waited on:
+// the non-zero chunks); *d_status is cleared first and receives the errors.  After the stream has been waited on:
 // report->unsettled == 0 is the usual case and the coefficients are final; otherwise
 // repair_entropy_decode has to run.
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
