@@ -291,6 +291,15 @@ def test_decode_long_streams_and_uneven_batch(ctx, po, jea):
         assert np.array_equal(got[i], po.decode(files[i], w, h, quality)), i
 
 
+def test_decode_stream_longer_than_the_folded_scan_covers(ctx, po, jea):
+    """Streams of more than 4096 chunks of 4 KiB take a separate scan launch between the unstuffing passes."""
+    w, h, quality = 2560, 1664, 100
+    lum, chrom = jea.binding.quant_tables(quality)
+    jpeg = po.encode(po.gen_image(w, h, 1, 21), quality)
+    assert len(jpeg) > 4097 * 4096
+    assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(jpeg, w, h, quality))
+
+
 @pytest.mark.parametrize("copies", [6, 20])
 def test_decode_batches_that_select_longer_subsequences(ctx, po, jea, copies):
     """The decoder cuts streams into sub-sequences of 2, 4 or 16 words depending on how much stream the
