@@ -41,38 +41,36 @@ __device__ __forceinline__ void colour_constants(int channel, double& k, double&
     c = channel == 0 ? 0.114 : (channel == 1 ? 0.5 : -0.081312);
 }
 
-// The same formulas in exact integer arithmetic.  All constants are multiples of 1/M with
-// M = 1000 for Y and M = 31250 for Cb, Cr (0.168736 = 5273/31250, 0.331264 = 10352/31250,
-// 0.5 = 15625/31250, 0.418688 = 13084/31250, 0.081312 = 2541/31250), so that
-//   value = t / M,   t = k + a r + b g + c b   an integer below 2^24 in magnitude,
-// and floor(value + 0.5) - 128 = floor((t + M/2 - 128 M) / M).  A rounding tie of the reference
-// (value + 0.5 an integer, where its double arithmetic decides and only the literal double
-// formula can tell which way) is a numerator that is a multiple of M; every other numerator is at
-// least 1/M = 3.2e-5 away from an integer quotient.
+// The same formulas without double arithmetic.  All constants are multiples of 1/M with M = 1000 for Y
+// and M = 31250 for Cb, Cr, so the exact value is t / M with t an integer, and the reference's result is
+// floor(t / M + 0.5) wherever its double arithmetic, whose error is some 1e-13, cannot land on the other
+// side of an integer: everywhere but at the ties, where t / M + 0.5 is itself an integer and only the
+// literal double formula can tell which way the reference rounds.
 //
-// The numerator is formed with three FMAs that are exact, with d*M added on top (d = 1.25e-4 for
-// Y: 0.125, d = 1.28e-4 for Cb, Cr: 4; both keep every intermediate exactly representable), and
-// divided by a multiply with RN(1/M): q is within 128 * 2^-23 < 3.1e-5 of (t / M) + d.  So
-//   fract(q) <  2d : t / M is within d + 3.1e-5 of an integer (every tie is: its fract(q) lies in
-//                    [d - 3.1e-5, d + 3.1e-5]) -> flagged, redone with colour_forward
-//   fract(q) >= 2d : t / M has a fractional part in (d - 3.1e-5, 1 - d + 3.1e-5), hence
-//                    floor(q) = floor(t / M), the reference's result; it needs no clamp because
-//                    an unflagged value + 0.5 lies strictly inside (0, 256).
+// Here q = value + 0.5 - 128 + d is formed by three f32 FMAs with constants rounded to f32; the
+// magnitudes stay below 256, so every rounding is at most 2^-17 and the constants contribute at most
+// 255 * 2^-24 in all: |q - true| < e = 4e-5.  With d = 1e-4 and the test fract(q) < 2e-4:
+//   every tie (true fraction exactly d) has fract(q) in [d - e, d + e] and is flagged;
+//   an unflagged q has a true fraction of at least 2e-4 - e > d, so the exact value + 0.5 - 128 lies in the
+//   same unit interval as q, and floor(q) is the reference's result (a q within e below an integer may
+//   belong to the next interval only if the true fraction is below e, which is flagged territory).
+// Flagged pixels (2e-4 of them, plus the ties: 1e-3 of the Y values) are redone with colour_forward.
+// An unflagged value + 0.5 lies strictly inside (0, 256), so no clamp is needed.  All 2^24 inputs of
+// every channel are compared with the oracle by the tests.
 struct ColourInt {
-    float k, a, b, c, rcp_m, window;
+    float k, a, b, c, window;
 };
 __device__ __forceinline__ ColourInt colour_int_constants(int channel) {
+    constexpr float d = 1e-4f;
     ColourInt ci;
-    // k = (constant term) * M + M/2 - 128 M + d M; for the chroma channels 128 M - 128 M cancels
-    if (channel == 0) ci = ColourInt{500.0f - 128000.0f + 0.125f, 299.0f, 587.0f, 114.0f, 1.0f / 1000.0f, 2.5e-4f};
-    else if (channel == 1) ci = ColourInt{15625.0f + 4.0f, -5273.0f, -10352.0f, 15625.0f, 1.0f / 31250.0f, 2.56e-4f};
-    else ci = ColourInt{15625.0f + 4.0f, 15625.0f, -13084.0f, -2541.0f, 1.0f / 31250.0f, 2.56e-4f};
+    if (channel == 0) ci = ColourInt{0.5f - 128.0f + d, 0.299f, 0.587f, 0.114f, 2e-4f};
+    else if (channel == 1) ci = ColourInt{0.5f + d, -0.168736f, -0.331264f, 0.5f, 2e-4f};
+    else ci = ColourInt{0.5f + d, 0.5f, -0.418688f, -0.081312f, 2e-4f};
     return ci;
 }
 // Level-shifted sample (value rounded, minus 128) as a float; `tie` is set when it must be redone.
 __device__ __forceinline__ float colour_forward_shifted_fast(const ColourInt& ci, float r, float g, float b, bool& tie) {
-    const float t = __builtin_fmaf(ci.c, b, __builtin_fmaf(ci.b, g, __builtin_fmaf(ci.a, r, ci.k)));
-    const float q = t * ci.rcp_m;
+    const float q = __builtin_fmaf(ci.c, b, __builtin_fmaf(ci.b, g, __builtin_fmaf(ci.a, r, ci.k)));
     const float fr = __builtin_amdgcn_fractf(q);      // q - floor(q), exact
     tie = fr < ci.window;
     return q - fr;
@@ -159,31 +157,22 @@ __device__ __forceinline__ void colour_inverse(int Y, int Cb, int Cr, uint8_t& r
     b = (uint8_t)round_to_range(y + 1.772 * cb);
 }
 
-// The same three formulas in exact arithmetic, by the method of colour_forward_shifted_fast.  With
-// cb = Cb - 128, cr = Cr - 128:
-//   R = floor((1000 Y + 1402 cr + 500) / 1000)          B likewise with 1772 cb
-//   G = Y + floor((62500 - 43017 cb - 89267 cr) / 125000)     (0.344136 = 43017/125000, 0.714136 = 89267/125000;
-//                                                              Y is an integer and may leave the floor)
-// wherever the reference's double arithmetic, whose error is some 1e-13, cannot land on the other side of
-// an integer, i.e. everywhere but at numerators that are multiples of M (ties).  Numerators are built by
-// exact FMAs with d*M added (0.125 for M = 1000; 16 for M = 125000, where the corner |cb|, |cr| ~ 128 passes
-// 2^24 and may be off by one unit: that is 8e-6 of a quotient and counted in the margin), divided by a
-// multiply with RN(1/M) -- quotients up to 482 resp. 136 in magnitude, so within 5.8e-5 resp. 2.5e-5 of the
-// true (t / M) + d, both well below d = 1.25e-4 resp. 1.28e-4 -- and flagged when fract(q) < 2.5e-4: every
-// tie has its fract(q) in [d - e, d + e], below that bound, and an unflagged quotient has
-// frac((t / M) + d) > 2.5e-4 - e > d, so that floor(q) = floor(t / M).  Values still need the clamp to
-// [0, 255] (:49-51); they are integers, so the conversion to bytes is exact.
+// The inverse formulas by the method of colour_forward_shifted_fast.  With cb = Cb - 128, cr = Cr - 128
+// the exact values are multiples of 1/1000 (R, B) and 1/125000 (G); q = value + 0.5 + d comes from one or
+// two f32 FMAs at magnitudes below 512 (roundings of at most 2^-16 each, constants 1.8 * 128 * 2^-24):
+// |q - true| < e = 5e-5 < d = 1e-4, and the test is fract(q) < 2e-4 as there.  Values still need the
+// clamp to [0, 255] (:49-51); they are integers, so the conversion to bytes is exact.
 __device__ __forceinline__ void colour_inverse_fast(float Y, float Cb, float Cr, float& r, float& g, float& b, bool& tie) {
     const float cb = Cb - 128.0f, cr = Cr - 128.0f;
-    const float y1000 = __builtin_fmaf(1000.0f, Y, 500.125f);
-    const float qr = __builtin_fmaf(1402.0f, cr, y1000) * (1.0f / 1000.0f);
-    const float qb = __builtin_fmaf(1772.0f, cb, y1000) * (1.0f / 1000.0f);
-    const float qg = __builtin_fmaf(-89267.0f, cr, __builtin_fmaf(-43017.0f, cb, 62516.0f)) * (1.0f / 125000.0f);
+    const float y = Y + (0.5f + 1e-4f);
+    const float qr = __builtin_fmaf(1.402f, cr, y);
+    const float qb = __builtin_fmaf(1.772f, cb, y);
+    const float qg = __builtin_fmaf(-0.714136f, cr, __builtin_fmaf(-0.344136f, cb, y));
     const float fr = __builtin_amdgcn_fractf(qr), fb = __builtin_amdgcn_fractf(qb), fg = __builtin_amdgcn_fractf(qg);
-    tie = min3(fr, fb, fg) < 2.5e-4f;
+    tie = min3(fr, fb, fg) < 2e-4f;
     r = __builtin_amdgcn_fmed3f(qr - fr, 0.0f, 255.0f);
     b = __builtin_amdgcn_fmed3f(qb - fb, 0.0f, 255.0f);
-    g = __builtin_amdgcn_fmed3f(Y + (qg - fg), 0.0f, 255.0f);
+    g = __builtin_amdgcn_fmed3f(qg - fg, 0.0f, 255.0f);
 }
 
 // byte `index` (0..3) of `word` replaced by the value, an integer in [0, 255] held as a float
