@@ -243,7 +243,8 @@ def main():
                        "%d x 3840x2160 RGB images encoded at q=75 per step" % args.batch,
                        "images_per_step": args.batch, "width": W, "height": H, "quality": QUALITY,
                        "jpeg_bytes_image0": size0, "byte_identical_to_oracle": parity,
-                       "streams": len(ctxs), "sharding": "images by rank, no collective"},
+                       "streams": len(ctxs), "sharding": "images by rank, no collective",
+                       "untimed_ramp_seconds_before_warmup": args.ramp_seconds},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
