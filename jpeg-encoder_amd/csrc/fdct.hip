@@ -79,18 +79,33 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
             for (int r = 0; r < 8; ++r) *reinterpret_cast<uint2*>(lds_in + r * 1536 + tid * 8) = v[r];
         }
     } else {
-        // any width: byte gather with the x and y clamps of block_grid.cpp:16-26
-        for (int i = tid; i < 8 * kMcusPerGroup * 24; i += kFdctThreads) {
-            const int r = i / 1536, rem = i - r * 1536;
-            const int m = rem / 24, byte = rem - m * 24;
-            const int px = byte / 3, comp = byte - px * 3;
-            if ((uint32_t)m < mcus_here) {
-                const uint32_t mcu = g0 + m;
-                const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
-                int y = (int)by * 8 + r, x = (int)bx * 8 + px;
+        // Any width or alignment: the same split of the work; MCUs that lie wholly inside the picture still
+        // load their row strips eight bytes at a time (unaligned loads), only the MCUs of a ragged last
+        // column gather bytes with the x clamp of block_grid.cpp:16-26 (the y clamp serves both).
+        const int m = tid / 3, part = tid - 3 * m;
+        if ((uint32_t)m < mcus_here) {
+            const uint32_t mcu = g0 + m;
+            const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+            const bool whole = (int)bx * 8 + 8 <= width;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                int y = (int)by * 8 + r;
                 y = y < height ? y : height - 1;
-                x = x < width ? x : width - 1;
-                lds_in[i] = img[((size_t)y * width + x) * 3 + comp];
+                const uint8_t* row = img + (size_t)y * width * 3;
+                uint2 v = make_uint2(0, 0);
+                if (whole) {
+                    __builtin_memcpy(&v, row + (size_t)bx * 24 + part * 8, 8);
+                } else {
+                    uint32_t w2[2] = {0, 0};
+                    for (int k = 0; k < 8; ++k) {
+                        const int byte = part * 8 + k, px = byte / 3, comp = byte - 3 * px;
+                        int x = (int)bx * 8 + px;
+                        x = x < width ? x : width - 1;
+                        w2[k >> 2] |= (uint32_t)row[(size_t)x * 3 + comp] << (8 * (k & 3));
+                    }
+                    v = make_uint2(w2[0], w2[1]);
+                }
+                *reinterpret_cast<uint2*>(lds_in + r * 1536 + tid * 8) = v;
             }
         }
     }
