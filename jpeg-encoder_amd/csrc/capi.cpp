@@ -9,10 +9,12 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/jpegenc_amd.h"
@@ -49,6 +51,9 @@ struct jea_ctx {
     // parallel decode
     DeviceBuffer ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
         round_flags, grp_pending, sub_guess, first_bad, ctx_keys, ctx_vals;
+    void* pin_io = nullptr;   // pinned staging for the host-buffer entry points
+    size_t pin_io_bytes = 0;
+    hipEvent_t piece_done[4] = {nullptr, nullptr, nullptr, nullptr};
     void* pinned = nullptr;   // host memory the GPU reads and writes: decode bookkeeping
     size_t pinned_bytes = 0;
     size_t stream_len = 0;
@@ -95,6 +100,73 @@ int ensure_pinned(jea_ctx* ctx, size_t bytes) {
     const size_t want = bytes + bytes / 8 + 4096;
     JEA_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
     ctx->pinned_bytes = want;
+    return JEA_OK;
+}
+
+int ensure_pin_io(jea_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->pin_io_bytes) {
+        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->pin_io) JEA_HIP(ctx, hipHostFree(ctx->pin_io));
+        ctx->pin_io = nullptr;
+        ctx->pin_io_bytes = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        JEA_HIP(ctx, hipHostMalloc(&ctx->pin_io, want, hipHostMallocDefault));
+        ctx->pin_io_bytes = want;
+    }
+    for (hipEvent_t& e : ctx->piece_done)
+        if (!e) JEA_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return JEA_OK;
+}
+
+// memcpy by a few threads: one thread moves some 10 GB/s, a PCIe link five times that
+void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kThreads = 4, kMinPerThread = 1u << 20;
+    if (bytes < 2 * kMinPerThread) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t piece = (bytes / kThreads + 63) & ~(size_t)63;
+    std::thread workers[kThreads - 1];
+    for (size_t t = 1; t < kThreads; ++t) {
+        const size_t at = t * piece, len = at < bytes ? (bytes - at < piece ? bytes - at : piece) : 0;
+        workers[t - 1] = std::thread([=] { if (len) std::memcpy((char*)dst + at, (const char*)src + at, len); });
+    }
+    std::memcpy(dst, src, piece < bytes ? piece : bytes);
+    for (std::thread& w : workers) w.join();
+}
+
+// Host to device through the pinned buffer in pieces: while one piece travels, the next is copied in.
+int upload_pipelined(jea_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    int rc;
+    if ((rc = ensure_pin_io(ctx, bytes))) return rc;
+    constexpr size_t kPieces = 4;
+    const size_t piece = ((bytes + kPieces - 1) / kPieces + 4095) & ~(size_t)4095;
+    for (size_t at = 0; at < bytes; at += piece) {
+        const size_t len = bytes - at < piece ? bytes - at : piece;
+        parallel_memcpy((char*)ctx->pin_io + at, (const char*)h_src + at, len);
+        JEA_HIP(ctx, hipMemcpyAsync((char*)d_dst + at, (char*)ctx->pin_io + at, len, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return JEA_OK;
+}
+
+// Device to host likewise; returns when h_dst is complete.
+int download_pipelined(jea_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    int rc;
+    if ((rc = ensure_pin_io(ctx, bytes))) return rc;
+    constexpr size_t kPieces = 2;   // measured: two pieces beat four on the way back
+    const size_t piece = ((bytes + kPieces - 1) / kPieces + 4095) & ~(size_t)4095;
+    size_t n = 0;
+    for (size_t at = 0; at < bytes; at += piece, ++n) {
+        const size_t len = bytes - at < piece ? bytes - at : piece;
+        JEA_HIP(ctx, hipMemcpyAsync((char*)ctx->pin_io + at, (const char*)d_src + at, len, hipMemcpyDeviceToHost, ctx->stream));
+        JEA_HIP(ctx, hipEventRecord(ctx->piece_done[n], ctx->stream));
+    }
+    n = 0;
+    for (size_t at = 0; at < bytes; at += piece, ++n) {
+        const size_t len = bytes - at < piece ? bytes - at : piece;
+        JEA_HIP(ctx, hipEventSynchronize(ctx->piece_done[n]));
+        parallel_memcpy((char*)h_dst + at, (const char*)ctx->pin_io + at, len);
+    }
     return JEA_OK;
 }
 
@@ -363,6 +435,9 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->ctx_vals})
         free_buffer(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
+    for (hipEvent_t e : ctx->piece_done)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_decode) (void)hipFree(ctx->d_decode);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
@@ -720,14 +795,12 @@ int jea_encode_host(jea_ctx* ctx, const uint8_t* h_rgb, uint16_t width, uint16_t
     int rc;
     if ((rc = ensure(ctx, ctx->stage_in, in_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->stage_out, cap))) return rc;
-    JEA_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, h_rgb, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload_pipelined(ctx, ctx->stage_in.ptr, h_rgb, in_bytes))) return rc;
     uint64_t off = 0, size = 0;
     rc = jea_encode_batch(ctx, (const uint8_t*)ctx->stage_in.ptr, 1, width, height, lum_q, chr_q,
                           (uint8_t*)ctx->stage_out.ptr, cap, &off, &size);
     if (rc) return rc;
-    JEA_HIP(ctx, hipMemcpyAsync(h_out, (const uint8_t*)ctx->stage_out.ptr + off, size, hipMemcpyDeviceToHost,
-                                ctx->stream));
-    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = download_pipelined(ctx, h_out, (const uint8_t*)ctx->stage_out.ptr + off, size))) return rc;
     *out_len = (size_t)size;
     return JEA_OK;
 }
@@ -981,9 +1054,7 @@ int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t wi
     rc = jea_decode_batch(ctx, (const uint8_t*)ctx->stage_out.ptr, &off, &size, 1, width, height, lum_q, chr_q,
                           (uint8_t*)ctx->stage_in.ptr);
     if (rc) return rc;
-    JEA_HIP(ctx, hipMemcpyAsync(h_rgb, ctx->stage_in.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return JEA_OK;
+    return download_pipelined(ctx, h_rgb, ctx->stage_in.ptr, out_bytes);
 }
 
 // ---- component-level entry points ---------------------------------------------
