@@ -569,12 +569,15 @@ void Encoder::encode(BitmapImageRGB const& inputImage, JPEGImage& outputImage) {
             inputImage.m_imageData.size() != static_cast<size_t>(inputImage.m_width) * inputImage.height)
             throw std::runtime_error("Input bitmap is empty or inconsistent");
         jea_ctx* ctx = context();
-        std::vector<uint8_t> file(jea_max_jpeg_bytes(inputImage.m_width, inputImage.height));
+        // worst case is some 19 bytes per pixel: the buffer is left uninitialised, so that only the pages the
+        // file really takes are ever touched
+        const size_t capacity = jea_max_jpeg_bytes(inputImage.m_width, inputImage.height);
+        std::unique_ptr<uint8_t[]> file(new uint8_t[capacity]);
         size_t fileLen = 0;
         check(ctx, jea_encode_host(ctx, reinterpret_cast<uint8_t const*>(inputImage.m_imageData.data()),
                                    inputImage.m_width, inputImage.height, m_quantiser->luminanceTable().data(),
-                                   m_quantiser->chrominanceTable().data(), file.data(), file.size(), &fileLen));
-        outputImage.m_compressedImageData.appendBytes(file.data(), fileLen);
+                                   m_quantiser->chrominanceTable().data(), file.get(), capacity, &fileLen));
+        outputImage.m_compressedImageData.appendBytes(file.get(), fileLen);
         outputImage.m_width = inputImage.m_width;
         outputImage.m_height = inputImage.height;
         outputImage.m_fileSize = outputImage.m_compressedImageData.getSize();
@@ -600,11 +603,23 @@ void Encoder::decode(JPEGImage inputImage, BitmapImageRGB& outputImage) {
         outputImage.m_width = headerWidth;
         if (inputImage.m_width == 0 || inputImage.m_height == 0) throw std::runtime_error("JPEG image has no dimensions");
         jea_ctx* ctx = context();
-        BitmapImageRGB decoded(inputImage.m_width, inputImage.m_height);
-        check(ctx, jea_decode_host(ctx, stream.getDataPtr(), len, inputImage.m_width, inputImage.m_height,
-                                   m_quantiser->luminanceTable().data(), m_quantiser->chrominanceTable().data(),
-                                   reinterpret_cast<uint8_t*>(decoded.m_imageData.data())));
-        outputImage = decoded;
+        // The library touches the caller's pixels only when the whole decode has succeeded, so an output
+        // that already has the right size is decoded into directly; otherwise into a fresh bitmap.
+        const size_t pixels = static_cast<size_t>(inputImage.m_width) * inputImage.m_height;
+        if (outputImage.m_imageData.size() == pixels) {
+            check(ctx, jea_decode_host(ctx, stream.getDataPtr(), len, inputImage.m_width, inputImage.m_height,
+                                       m_quantiser->luminanceTable().data(), m_quantiser->chrominanceTable().data(),
+                                       reinterpret_cast<uint8_t*>(outputImage.m_imageData.data())));
+            outputImage.m_width = inputImage.m_width;
+            outputImage.height = inputImage.m_height;
+            outputImage.m_fileSize = 0;   // as a bitmap made by the (width, height) constructor
+        } else {
+            BitmapImageRGB decoded(inputImage.m_width, inputImage.m_height);
+            check(ctx, jea_decode_host(ctx, stream.getDataPtr(), len, inputImage.m_width, inputImage.m_height,
+                                       m_quantiser->luminanceTable().data(), m_quantiser->chrominanceTable().data(),
+                                       reinterpret_cast<uint8_t*>(decoded.m_imageData.data())));
+            outputImage = std::move(decoded);
+        }
     } catch (std::exception const& e) {
         std::cout << "[Error]: " << e.what() << "\n";
     }

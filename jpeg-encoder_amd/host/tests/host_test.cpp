@@ -4,6 +4,7 @@
 // GPU test compares with the oracle's.  Also drives the per-block component
 // methods through the reference's own loop structure (encoder.cpp:14-42) and
 // checks that they give the same file as the fused path.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -177,6 +178,21 @@ int main(int argc, char** argv) {
         jpeg::JPEGImage jpg;
         custom.encode(bmp, jpg);
         std::printf("no_device_path_size %zu\n", jpg.m_compressedImageData.getSize());
+    }
+    {   // wall time of the two calls a user of the classes makes, on a 3840x2160 picture
+        jpeg::BitmapImageRGB bmp = make_image(3840, 2160, 0, 1234);
+        jpeg::BaselineEncoder encoder(75);
+        jpeg::JPEGImage jpg;
+        jpeg::BitmapImageRGB dec;
+        for (int it = 0; it < 4; ++it) {
+            const auto t0 = std::chrono::steady_clock::now();
+            encoder.encode(bmp, jpg);
+            const auto t1 = std::chrono::steady_clock::now();
+            encoder.decode(jpg, dec);
+            const auto t2 = std::chrono::steady_clock::now();
+            std::printf("timing_4k encode_ms %.2f decode_ms %.2f\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                        std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
     }
     {   // damaged header: the reference's message on stdout, output untouched
         jpeg::BitmapImageRGB bmp = make_image(16, 16, 0, 1);
