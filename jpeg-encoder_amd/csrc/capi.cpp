@@ -125,7 +125,7 @@ void parallel_memcpy(void* dst, const void* src, size_t bytes) {
         std::memcpy(dst, src, bytes);
         return;
     }
-    const size_t piece = (bytes / kThreads + 63) & ~(size_t)63;
+    const size_t piece = ((bytes + kThreads - 1) / kThreads + 63) & ~(size_t)63;
     std::thread workers[kThreads - 1];
     for (size_t t = 1; t < kThreads; ++t) {
         const size_t at = t * piece, len = at < bytes ? (bytes - at < piece ? bytes - at : piece) : 0;

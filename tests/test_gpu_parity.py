@@ -555,3 +555,14 @@ def test_random_shapes_qualities_and_contents(ctx, po, jea):
         want = po.encode(rgb, quality)
         assert bytes(ctx.encode_host(rgb, lum, chrom)) == want, (i, w, h, quality, kind)
         assert np.array_equal(ctx.decode_host(want, w, h, lum, chrom), po.decode(want, w, h, quality)), (i, w, h, quality, kind)
+
+
+def test_host_buffers_large_enough_for_the_threaded_copy(ctx, po, jea):
+    """Above a few megabytes the host-buffer entry points move the caller's data in pieces and with several
+    threads; sizes that do not divide evenly must still arrive whole."""
+    for w, h in [(1277, 911), (2049, 1025), (2048, 1024), (1365, 1027)]:
+        rgb = po.gen_image(w, h, 1, 77)
+        lum, chrom = jea.binding.quant_tables(90)
+        want = po.encode(rgb, 90)
+        assert bytes(ctx.encode_host(rgb, lum, chrom)) == want, (w, h)
+        assert np.array_equal(ctx.decode_host(want, w, h, lum, chrom), po.decode(want, w, h, 90)), (w, h)
