@@ -51,6 +51,7 @@ struct jea_ctx {
     // parallel decode
     DeviceBuffer ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
         round_flags, grp_pending, sub_guess, first_bad, ctx_keys, ctx_vals;
+    DeviceBuffer tile_ff8;
     void* pin_io = nullptr;   // pinned staging for the host-buffer entry points
     size_t pin_io_bytes = 0;
     hipEvent_t piece_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -295,6 +296,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     if ((rc = ensure(ctx, ctx->tile_ff, n_images * n_tiles * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->tile_ffbase, n_images * n_tiles * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->img_words, 3 * n_images * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->tile_ff8, n_tiles * 8 * sizeof(uint32_t)))) return rc;
     // The packed stream of an image is never longer than its stuffed one.
     const size_t worst = n_images * ((nbc * 1660 + 7) / 8 + 16);
     const size_t ucap = (out_capacity + 16 * n_images < worst) ? out_capacity + 16 * n_images : worst;
@@ -313,6 +315,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     sc.img_ff = sc.img_ubase + n_images;
     sc.unstuffed = (uint8_t*)ctx->unstuffed.ptr;
     sc.unstuffed_capacity = ucap;
+    sc.tile_ff8 = (uint32_t*)ctx->tile_ff8.ptr;
     return JEA_OK;
 }
 
@@ -432,7 +435,7 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->ustream, &ctx->chunk_drops, &ctx->chunk_base, &ctx->img_drops,
                             &ctx->sub_end, &ctx->sub_used, &ctx->sub_info, &ctx->grp_sum, &ctx->grp_base,
                             &ctx->round_flags, &ctx->grp_pending, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
-                            &ctx->ctx_vals})
+                            &ctx->ctx_vals, &ctx->tile_ff8})
         free_buffer(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);

@@ -460,6 +460,257 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
     }
 }
 
+// ---------------------------------------------------------------------------
+// One image, two launches instead of three.  Where a tile's bytes go in the file depends on the 0xFF bytes
+// before it, and which bytes are 0xFF depends on how the tile's bits fall on the byte grid: on the bit
+// total of the tiles before it, modulo 8.  So the first kernel, besides the blocks' bit strings, lays the
+// tile's string out in LDS at bit offset 0 and counts, for each of the eight offsets the tile may end up at,
+// the 0xFF bytes it would own; the second kernel gets the 0xFF prefix from those counts while it sums the
+// bit totals, and stuffs straight out of its LDS window.  No unstuffed copy in memory, no third launch.
+// ---------------------------------------------------------------------------
+
+// ORs every thread's string (my_len bits in slot words, starting `start` bits into the window's word 0 of
+// window pass wlo) into win[0 .. kWinWords]; word kWinWords is complete too, as the successor of the last.
+__device__ __forceinline__ void or_strings(uint32_t* win, const uint32_t* __restrict__ slot, uint32_t my_len,
+                                           uint32_t start, uint32_t wlo) {
+    const uint32_t my_words = (my_len + 31) >> 5, sh = start & 31u, first = start >> 5;
+    for (uint32_t w = 0; w < my_words; ++w) {
+        const uint32_t idx = first + w - wlo;        // wraps below the window: rejected by the range tests
+        if (idx <= kWinWords || idx == 0xffffffffu) {
+            const uint32_t v = slot[(size_t)w * kSlotStride];
+            if (idx <= kWinWords) atomicOr(&win[idx], v >> sh);
+            if (sh != 0 && idx + 1 <= kWinWords) atomicOr(&win[idx + 1], v << (32u - sh));
+        }
+    }
+}
+
+template <bool kPlanar>
+__global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+                                                                const HuffTables* __restrict__ huff,
+                                                                const uint8_t* __restrict__ chunk_masks,
+                                                                ComponentMode mode, uint16_t* __restrict__ len16,
+                                                                uint32_t* __restrict__ slots,
+                                                                uint32_t* __restrict__ tile_bits,
+                                                                uint4* __restrict__ tile_ff8,
+                                                                int32_t* __restrict__ status) {
+    __shared__ HuffLds h;
+    __shared__ uint32_t win[kWinWords + 2];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t count[8], own_bits;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t b = tile * kTileBlocks + threadIdx.x;
+    // 252 own block-channels, and the first MCU of the next tile once more (threads 252..254): the byte that
+    // straddles two tiles belongs to the earlier one, whose 0xFF count needs those bits
+    const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
+    BlockRegs blk;
+    const int ch = (int)(b % 3u);
+    int prev_dc = 0;
+    if (has_block) {
+        if (kPlanar) {
+            const uint32_t n_mcu = nbc / 3u, mcu = b / 3u;
+            const uint4* q = reinterpret_cast<const uint4*>(coefs) + (size_t)ch * n_mcu + mcu;
+            load_block_planar(blk, q, (size_t)3 * n_mcu, (uint32_t)chunk_masks[b]);
+            prev_dc = (b >= 3) ? (int)*reinterpret_cast<const int16_t*>(q - 1) : 0;
+        } else {
+            const int16_t* p = coefs + (size_t)b * 64;
+            load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[b] : 0xffu);
+            prev_dc = (b >= 3) ? (int)p[-192] : 0;
+        }
+    }
+    load_huff(h, huff);
+    if (threadIdx.x < 8) count[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t* const slot = slots + (size_t)tile * kSlotWords * kSlotStride + threadIdx.x;
+    uint32_t my_len = 0;
+    if (has_block) {
+        const int cls = mode.is_lum((uint32_t)ch) ? 0 : 1;   // Huffman table class (encoder.cpp:25)
+        SlotSink sink;
+        sink.slot = slot;
+        if (!encode_block(blk, prev_dc, h.dc[cls], h.ac[cls], sink)) atomicExch(status, JEA_ERR_RANGE);
+        sink.finish();
+        my_len = sink.bits;
+        if (threadIdx.x < kTileBlocks) len16[b] = (uint16_t)my_len;
+    }
+    uint32_t with_next;
+    const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, with_next);   // has barriers
+    if (threadIdx.x == kTileBlocks) {   // its prefix is the total of the tile's own blocks
+        own_bits = local_off;
+        tile_bits[tile] = local_off;
+    }
+    __syncthreads();
+    const uint32_t n_own = own_bits;
+
+    // Bit p of the tile's string (offset 0) starts a 0xFF byte for the alignments that put a byte boundary
+    // there, if bits p .. p+7 are ones; the tile owns the bytes that start inside it, p < n_own.  Counts by
+    // p mod 8.  Past the tile's end the window holds the next MCU's bits, then zeros (as the padding is).
+    const uint32_t n_words = (n_own + 31) >> 5;
+    for (uint32_t wlo = 0; wlo < n_words; wlo += kWinWords) {
+        const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
+        for (uint32_t i = threadIdx.x; i < words_here + 1; i += kEntThreads) win[i] = 0;
+        __syncthreads();
+        or_strings(win, slot, my_len, local_off, wlo);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < words_here; i += kEntThreads) {
+            const unsigned long long v = ((unsigned long long)win[i] << 32) | win[i + 1];
+            const unsigned long long a = v & (v << 1), c2 = a & (a << 2), c4 = c2 & (c2 << 4);
+            uint32_t m = (uint32_t)(c4 >> 32);                    // bit 31-j: eight ones start at bit j of this word
+            const uint32_t p0 = 32u * (wlo + i);
+            if (p0 + 32u > n_own) m &= ~0u << (p0 + 32u - n_own);  // positions inside the tile only (p0 < n_own here)
+            if (m != 0) {
+#pragma unroll
+                for (uint32_t r = 0; r < 8; ++r) {
+                    const uint32_t n = (uint32_t)__popc(m & (0x80808080u >> r));
+                    if (n) atomicAdd(&count[r], n);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)   // eight 16-bit counts: a tile has at most 252 * 1660 / 8 bytes
+        tile_ff8[tile] = make_uint4(count[0] | count[1] << 16, count[2] | count[3] << 16, count[4] | count[5] << 16,
+                                    count[6] | count[7] << 16);
+}
+
+// The count for tiles whose bit base is `base_bits`: byte boundaries fall on the tile's bits p = -base mod 8.
+__device__ __forceinline__ uint32_t ff_at(const uint4& f, uint32_t base_bits) {
+    const uint32_t r = (8u - (base_bits & 7u)) & 7u;
+    // by shifts: a choice among the four words turns into an indexed load from a copy in scratch memory
+    const uint64_t lo = (uint64_t)f.x | (uint64_t)f.y << 32, hi = (uint64_t)f.z | (uint64_t)f.w << 32;
+    return (uint32_t)(((r & 4u) ? hi : lo) >> (16u * (r & 3u))) & 0xffffu;
+}
+
+__global__ __launch_bounds__(kEntThreads) void pack_stuff_kernel(uint32_t nbc, uint32_t n_tiles,
+                                                                 const uint32_t* __restrict__ slots,
+                                                                 const uint16_t* __restrict__ len16,
+                                                                 const uint32_t* __restrict__ tile_bits,
+                                                                 const uint4* __restrict__ tile_ff8,
+                                                                 uint64_t* __restrict__ offsets,
+                                                                 uint64_t* __restrict__ sizes, HeaderBytes header,
+                                                                 uint32_t header_len, uint32_t with_eoi,
+                                                                 uint8_t* __restrict__ out, uint64_t out_capacity,
+                                                                 int32_t* __restrict__ status) {
+    __shared__ uint32_t win[kWinWords + 2];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint64_t lsum[8];
+    const uint32_t tile = blockIdx.x;
+    const int32_t status_now = *status;
+    // Tiles before this one, a contiguous run of them per thread: their bit totals give the bit base of each
+    // (after one scan over the threads), its alignment, and with that its 0xFF count.
+    const uint32_t per_thread = (tile + kEntThreads - 1) / kEntThreads;
+    const uint32_t j0 = threadIdx.x * per_thread, j1 = (j0 + per_thread < tile) ? j0 + per_thread : tile;
+    // Up to kRun tiles per thread (any picture up to 1536 tiles, a 4K one has 1286): everything is loaded
+    // before the scan, all eight counts of each tile, so that no load waits for the scan's result.
+    constexpr uint32_t kRun = 6;
+    const bool short_run = per_thread <= kRun;
+    uint32_t run_bits = 0, rb[kRun];
+    uint4 rf[kRun];
+    if (short_run) {
+#pragma unroll
+        for (uint32_t u = 0; u < kRun; ++u) {
+            const bool in = j0 + u < j1;
+            rb[u] = in ? tile_bits[j0 + u] : 0u;
+            rf[u] = in ? tile_ff8[j0 + u] : make_uint4(0, 0, 0, 0);
+            run_bits += rb[u];
+        }
+    } else {
+        for (uint32_t j = j0; j < j1; ++j) run_bits += tile_bits[j];
+    }
+    const uint32_t own_bits = tile_bits[tile];
+    const uint4 own_ff8 = tile_ff8[tile];
+    const uint32_t b = tile * kTileBlocks + threadIdx.x;
+    const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
+    const uint32_t my_len = has_block ? len16[b] : 0u;
+    if (status_now != 0) return;
+    uint32_t bits_before;   // fits: at most 4096 tiles of 252 * 1660 bits
+    uint32_t running = block_exclusive_scan_256(run_bits, wsum, bits_before);
+    uint64_t ff_run = 0, unused = 0;
+    if (short_run) {
+#pragma unroll
+        for (uint32_t u = 0; u < kRun; ++u) {
+            ff_run += ff_at(rf[u], running);
+            running += rb[u];
+        }
+    } else {
+        for (uint32_t j = j0; j < j1; ++j) {
+            ff_run += ff_at(tile_ff8[j], running);
+            running += tile_bits[j];
+        }
+    }
+    fold_reduce(ff_run, unused, lsum);
+    const uint64_t ff_before = ff_run;
+    const uint64_t base_bits = bits_before, end_bits = base_bits + own_bits;
+    const uint32_t own_ff = ff_at(own_ff8, bits_before);
+    const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1) of the unstuffed stream
+    const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
+    if (header_len + b1 + ff_before + own_ff + tail > out_capacity) {
+        if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
+        return;
+    }
+    if (tile + 1 == n_tiles && threadIdx.x == 0) {
+        offsets[0] = 0;
+        sizes[0] = header_len + b1 + ff_before + own_ff + tail;
+    }
+    if (tile == 0)
+        for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) out[i] = header.b[i];
+    if (tile + 1 == n_tiles && with_eoi && threadIdx.x == 0) {
+        uint8_t* e = out + header_len + b1 + ff_before + own_ff;
+        e[0] = 0xFF;
+        e[1] = 0xD9;
+    }
+
+    uint32_t tile_total;
+    const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);
+    const uint64_t d0 = base_bits >> 5;                      // image-relative dword of window word 0
+    const uint32_t rel_start = (uint32_t)(base_bits & 31) + local_off;
+    const uint32_t n_words = (uint32_t)((b1 * 8 - d0 * 32 + 31) >> 5);  // words that hold owned bytes
+    // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
+    const uint32_t slot_tile = threadIdx.x < kTileBlocks ? tile : tile + 1;
+    const uint32_t slot_col = threadIdx.x < kTileBlocks ? threadIdx.x : threadIdx.x - kTileBlocks;
+    const uint32_t* slot = slots + (size_t)slot_tile * kSlotWords * kSlotStride + slot_col;
+    uint8_t* const dst = out + header_len + ff_before;       // + stream byte index + 0xFFs of this tile before it
+    uint64_t carry = 0;
+    for (uint32_t wlo = 0; wlo < n_words; wlo += kWinWords) {
+        const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
+        for (uint32_t i = threadIdx.x; i < words_here + 1; i += kEntThreads) win[i] = 0;
+        __syncthreads();
+        or_strings(win, slot, my_len, rel_start, wlo);
+        __syncthreads();
+        // sixteen bytes (four words) per thread and step, bit_stream.cpp:127-134 (intended semantics)
+        for (uint32_t w0 = 0; w0 < words_here; w0 += kEntThreads * 4) {
+            const uint32_t wi = w0 + threadIdx.x * 4;
+            uint32_t bytes[16];
+            uint32_t owned = 0, cnt = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) {
+                const uint32_t word = wi + (k >> 2);
+                const uint64_t x = (d0 + wlo + word) * 4 + (k & 3);      // stream byte index
+                const uint32_t v = word < words_here ? win[word] : 0u;
+                bytes[k] = (v >> (24 - 8 * (k & 3))) & 0xffu;
+                if (word < words_here && x >= b0 && x < b1) {
+                    owned |= 1u << k;
+                    cnt += bytes[k] == 0xffu;
+                }
+            }
+            uint32_t total;
+            uint64_t pos = carry + block_exclusive_scan_256(cnt, wsum, total);
+            const uint64_t x0 = (d0 + wlo + wi) * 4;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) {
+                if ((owned >> k) & 1u) {
+                    dst[x0 + k + pos] = (uint8_t)bytes[k];
+                    if (bytes[k] == 0xffu) {
+                        ++pos;
+                        dst[x0 + k + pos] = 0x00;
+                    }
+                }
+            }
+            carry += total;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -480,6 +731,19 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const dim3 grid(n_tiles, (unsigned)n_images);
     const uint32_t n = (uint32_t)n_images;
     const uint32_t eoi = with_eoi ? 1u : 0u;
+
+    if (n == 1 && n_tiles <= kFoldTiles) {
+        if (sc.planar)
+            tile_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, d_huff, sc.chunk_masks, sc.mode, sc.len16,
+                                                                sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8, d_status);
+        else
+            tile_bits_kernel<false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, d_huff, sc.chunk_masks, sc.mode, sc.len16,
+                                                                 sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8, d_status);
+        pack_stuff_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, (const uint4*)sc.tile_ff8,
+                                                       d_offsets, d_sizes, header, (uint32_t)header_len, eoi, d_out,
+                                                       out_capacity, d_status);
+        return;
+    }
 
     if (sc.planar)
         block_bits_kernel<true, true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
