@@ -494,9 +494,9 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
                                                                 uint4* __restrict__ tile_ff8,
                                                                 int32_t* __restrict__ status) {
     __shared__ HuffLds h;
-    __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t count[8], own_bits;
+    __shared__ uint32_t count[8];
+    __shared__ uint32_t lens[kEntThreads];
     const uint32_t tile = blockIdx.x;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     // 252 own block-channels, and the first MCU of the next tile once more (threads 252..254): the byte that
@@ -532,41 +532,44 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
         my_len = sink.bits;
         if (threadIdx.x < kTileBlocks) len16[b] = (uint16_t)my_len;
     }
+    lens[threadIdx.x] = my_len;
     uint32_t with_next;
     const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, with_next);   // has barriers
-    if (threadIdx.x == kTileBlocks) {   // its prefix is the total of the tile's own blocks
-        own_bits = local_off;
-        tile_bits[tile] = local_off;
-    }
-    __syncthreads();
-    const uint32_t n_own = own_bits;
+    if (threadIdx.x == kTileBlocks) tile_bits[tile] = local_off;   // its prefix is the total of the tile's own blocks
 
-    // Bit p of the tile's string (offset 0) starts a 0xFF byte for the alignments that put a byte boundary
-    // there, if bits p .. p+7 are ones; the tile owns the bytes that start inside it, p < n_own.  Counts by
-    // p mod 8.  Past the tile's end the window holds the next MCU's bits, then zeros (as the padding is).
-    const uint32_t n_words = (n_own + 31) >> 5;
-    for (uint32_t wlo = 0; wlo < n_words; wlo += kWinWords) {
-        const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
-        for (uint32_t i = threadIdx.x; i < words_here + 1; i += kEntThreads) win[i] = 0;
-        __syncthreads();
-        or_strings(win, slot, my_len, local_off, wlo);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < words_here; i += kEntThreads) {
-            const unsigned long long v = ((unsigned long long)win[i] << 32) | win[i + 1];
-            const unsigned long long a = v & (v << 1), c2 = a & (a << 2), c4 = c2 & (c2 << 4);
-            uint32_t m = (uint32_t)(c4 >> 32);                    // bit 31-j: eight ones start at bit j of this word
-            const uint32_t p0 = 32u * (wlo + i);
-            if (p0 + 32u > n_own) m &= ~0u << (p0 + 32u - n_own);  // positions inside the tile only (p0 < n_own here)
-            if (m != 0) {
+    // Bit p of the tile's string starts a 0xFF byte for the alignments that put a byte boundary there, if bits
+    // p .. p+7 are ones; the tile owns the bytes that start inside it.  Each thread reads its string back, with
+    // the seven bits that follow it: those are in the next two strings (a block's string has at least four
+    // bits; past the picture's end the padding is zeros).  Tallies go from the string's positions to the tile's.
+    if (threadIdx.x < kTileBlocks && has_block) {
+        const uint32_t len1 = lens[threadIdx.x + 1], len2 = lens[threadIdx.x + 2];
+        const uint32_t head1 = len1 ? slot[1] : 0u, head2 = (len1 < 32 && len2) ? slot[2] : 0u;
+        const uint32_t following = head1 | (len1 < 32 ? head2 >> len1 : 0u);
+        const uint32_t n_words = (my_len + 31) >> 5, rem = my_len & 31u;
+        // the partial last word is filled up with the following bits; after it come the rest of those
+        const uint32_t after = rem ? following << (32u - rem) : following;
+        uint32_t cur = slot[0];
+        if (n_words == 1 && rem) cur |= following >> rem;
+        uint64_t t = 0;
+        for (uint32_t i = 0; i < n_words; ++i) {
+            uint32_t next = after;
+            if (i + 1 < n_words) {
+                next = slot[(size_t)(i + 1) * kSlotStride];
+                if (i + 2 == n_words && rem) next |= following >> rem;
+            }
+            t += ff_places(cur, next, (i + 1 == n_words && rem) ? ~0u << (32u - rem) : ~0u);
+            cur = next;
+        }
+        if (t != 0) {
+            const uint32_t shift = local_off & 7u;
 #pragma unroll
-                for (uint32_t r = 0; r < 8; ++r) {
-                    const uint32_t n = (uint32_t)__popc(m & (0x80808080u >> r));
-                    if (n) atomicAdd(&count[r], n);
-                }
+            for (uint32_t r = 0; r < 8; ++r) {
+                const uint32_t n = (uint32_t)(t >> (8u * r)) & 0xffu;
+                if (n) atomicAdd(&count[(r + shift) & 7u], n);
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (threadIdx.x == 0)   // eight 16-bit counts: a tile has at most 252 * 1660 / 8 bytes
         tile_ff8[tile] = make_uint4(count[0] | count[1] << 16, count[2] | count[3] << 16, count[4] | count[5] << 16,
                                     count[6] | count[7] << 16);

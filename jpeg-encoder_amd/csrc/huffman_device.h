@@ -146,6 +146,21 @@ struct SlotSink {
     }
 };
 
+// Places j of w0 (bit 31-j), within `valid`, from which on w0:w1 holds eight ones: where a 0xFF byte starts if
+// a byte boundary falls there.  Returned as eight 8-bit tallies by j mod 8 (at most four each).
+__device__ __forceinline__ uint64_t ff_places(uint32_t w0, uint32_t w1, uint32_t valid) {
+    // runs of 2, 4, 8 ones by doubling; of the low word only the top bits matter, which its own shifts get right
+    const uint32_t a0 = w0 & __builtin_amdgcn_alignbit(w0, w1, 31), a1 = w1 & (w1 << 1);
+    const uint32_t b0 = a0 & __builtin_amdgcn_alignbit(a0, a1, 30), b1 = a1 & (a1 << 2);
+    const uint32_t m = b0 & __builtin_amdgcn_alignbit(b0, b1, 28) & valid;
+    uint64_t t = 0;
+    if (m != 0) {
+#pragma unroll
+        for (uint32_t r = 0; r < 8; ++r) t |= (uint64_t)__popc(m & (0x80808080u >> r)) << (8u * r);
+    }
+    return t;
+}
+
 struct SerialReader {
     const uint8_t* lds;     // staged raw bytes [base, base + kStreamWin + 16)
     uint64_t base;          // file-relative index of lds[0]
