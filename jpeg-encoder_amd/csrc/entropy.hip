@@ -551,14 +551,24 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
         uint32_t cur = slot[0];
         if (n_words == 1 && rem) cur |= following >> rem;
         uint64_t t = 0;
-        for (uint32_t i = 0; i < n_words; ++i) {
-            uint32_t next = after;
-            if (i + 1 < n_words) {
-                next = slot[(size_t)(i + 1) * kSlotStride];
-                if (i + 2 == n_words && rem) next |= following >> rem;
+        for (uint32_t i0 = 0; i0 < n_words; i0 += 4) {   // four loads under way at a time
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                w[k] = (i0 + k + 1 < n_words) ? slot[(size_t)(i0 + k + 1) * kSlotStride] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t i = i0 + k;
+                if (i < n_words) {
+                    uint32_t next = after;
+                    if (i + 1 < n_words) {
+                        next = w[k];
+                        if (i + 2 == n_words && rem) next |= following >> rem;
+                    }
+                    t += ff_places(cur, next, (i + 1 == n_words && rem) ? ~0u << (32u - rem) : ~0u);
+                    cur = next;
+                }
             }
-            t += ff_places(cur, next, (i + 1 == n_words && rem) ? ~0u << (32u - rem) : ~0u);
-            cur = next;
         }
         if (t != 0) {
             const uint32_t shift = local_off & 7u;
@@ -583,7 +593,7 @@ __device__ __forceinline__ uint32_t ff_at(const uint4& f, uint32_t base_bits) {
     return (uint32_t)(((r & 4u) ? hi : lo) >> (16u * (r & 3u))) & 0xffffu;
 }
 
-__global__ __launch_bounds__(kEntThreads) void pack_stuff_kernel(uint32_t nbc, uint32_t n_tiles,
+__global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc, uint32_t n_tiles,
                                                                  const uint32_t* __restrict__ slots,
                                                                  const uint16_t* __restrict__ len16,
                                                                  const uint32_t* __restrict__ tile_bits,
@@ -594,8 +604,7 @@ __global__ __launch_bounds__(kEntThreads) void pack_stuff_kernel(uint32_t nbc, u
                                                                  uint8_t* __restrict__ out, uint64_t out_capacity,
                                                                  int32_t* __restrict__ status) {
     __shared__ uint32_t win[kWinWords + 2];
-    __shared__ uint32_t wsum[4];
-    __shared__ uint64_t lsum[8];
+    __shared__ uint32_t wsum[4], psum[8], fsum[4];
     const uint32_t tile = blockIdx.x;
     const int32_t status_now = *status;
     // Tiles before this one, a contiguous run of them per thread: their bit totals give the bit base of each
@@ -625,9 +634,34 @@ __global__ __launch_bounds__(kEntThreads) void pack_stuff_kernel(uint32_t nbc, u
     const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
     const uint32_t my_len = has_block ? len16[b] : 0u;
     if (status_now != 0) return;
-    uint32_t bits_before;   // fits: at most 4096 tiles of 252 * 1660 bits
-    uint32_t running = block_exclusive_scan_256(run_bits, wsum, bits_before);
-    uint64_t ff_run = 0, unused = 0;
+    // one scan for both: the runs' bit totals (a) and the lengths of this tile's strings (b)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl_a = run_bits, incl_b = my_len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ta = __shfl_up(incl_a, d), tb = __shfl_up(incl_b, d);
+        if (lane >= d) {
+            incl_a += ta;
+            incl_b += tb;
+        }
+    }
+    if (lane == 63) {
+        psum[wave] = incl_a;
+        psum[4 + wave] = incl_b;
+    }
+    __syncthreads();
+    uint32_t base_a = 0, base_b = 0, bits_before = 0;   // fits: at most 4096 tiles of 252 * 1660 bits
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) {
+            base_a += psum[w];
+            base_b += psum[4 + w];
+        }
+        bits_before += psum[w];
+    }
+    uint32_t running = base_a + incl_a - run_bits;
+    const uint32_t local_off = base_b + incl_b - my_len;
+    uint32_t ff_run = 0;
     if (short_run) {
 #pragma unroll
         for (uint32_t u = 0; u < kRun; ++u) {
@@ -640,8 +674,11 @@ __global__ __launch_bounds__(kEntThreads) void pack_stuff_kernel(uint32_t nbc, u
             running += tile_bits[j];
         }
     }
-    fold_reduce(ff_run, unused, lsum);
-    const uint64_t ff_before = ff_run;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ff_run += __shfl_xor(ff_run, d);
+    if (lane == 0) fsum[wave] = ff_run;
+    __syncthreads();
+    const uint64_t ff_before = (uint64_t)fsum[0] + fsum[1] + fsum[2] + fsum[3];
     const uint64_t base_bits = bits_before, end_bits = base_bits + own_bits;
     const uint32_t own_ff = ff_at(own_ff8, bits_before);
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1) of the unstuffed stream
@@ -662,8 +699,6 @@ __global__ __launch_bounds__(kEntThreads) void pack_stuff_kernel(uint32_t nbc, u
         e[1] = 0xD9;
     }
 
-    uint32_t tile_total;
-    const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);
     const uint64_t d0 = base_bits >> 5;                      // image-relative dword of window word 0
     const uint32_t rel_start = (uint32_t)(base_bits & 31) + local_off;
     const uint32_t n_words = (uint32_t)((b1 * 8 - d0 * 32 + 31) >> 5);  // words that hold owned bytes
