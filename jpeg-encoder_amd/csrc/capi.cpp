@@ -296,7 +296,7 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
     if ((rc = ensure(ctx, ctx->tile_ff, n_images * n_tiles * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->tile_ffbase, n_images * n_tiles * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->img_words, 3 * n_images * sizeof(uint64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->tile_ff8, n_tiles * 8 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->tile_ff8, n_images * n_tiles * 4 * sizeof(uint32_t)))) return rc;
     // The packed stream of an image is never longer than its stuffed one.
     const size_t worst = n_images * ((nbc * 1660 + 7) / 8 + 16);
     const size_t ucap = (out_capacity + 16 * n_images < worst) ? out_capacity + 16 * n_images : worst;

@@ -45,6 +45,7 @@ namespace {
 constexpr int kEntThreads = 256;
 constexpr uint32_t kWinWords = 4096;  // 16 KiB LDS window of the packed stream
 constexpr uint32_t kFoldTiles = 4096;  // single images up to this many tiles skip the scan launches
+constexpr uint32_t kLatencyTiles = 32768;  // launches of more tiles than this are bound by throughput
 
 // Exclusive scan of one value per thread over a 256-thread workgroup.
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* lds4, uint32_t& total) {
@@ -230,32 +231,6 @@ __global__ __launch_bounds__(1024) void scan_images_kernel(uint32_t n_images, co
     }
 }
 
-// Single images with few tiles skip the scan launches: each workgroup adds up the totals of the
-// tiles before it.  The loads are issued first thing in the kernel (fold_partial) and reduced where the
-// sum is needed (fold_reduce), so that their latency hides behind the kernel's other loads.
-__device__ __forceinline__ uint64_t fold_partial(const uint32_t* __restrict__ arr, uint32_t count) {
-    uint64_t v = 0;
-    for (uint32_t i = threadIdx.x; i < count; i += kEntThreads) v += arr[i];
-    return v;
-}
-// Sums a and b over the 256 threads of the workgroup (every thread gets both results).
-__device__ __forceinline__ void fold_reduce(uint64_t& a, uint64_t& b, uint64_t* lds8) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        a += __shfl_xor(a, d);
-        b += __shfl_xor(b, d);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        lds8[threadIdx.x >> 6] = a;
-        lds8[4 + (threadIdx.x >> 6)] = b;
-    }
-    __syncthreads();
-    a = lds8[0] + lds8[1] + lds8[2] + lds8[3];
-    b = lds8[4] + lds8[5] + lds8[6] + lds8[7];
-    __syncthreads();
-}
-
-template <bool kFold>
 __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_t n_tiles,
                                                            const uint32_t* __restrict__ slots,
                                                            const uint16_t* __restrict__ len16,
@@ -269,11 +244,9 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
                                                            int32_t* __restrict__ status, StripeInfo st) {
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4];
-    __shared__ uint64_t lsum[8];
     __shared__ uint32_t ff_count;
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const int32_t status_now = *status;                       // looked at after the other loads are under way
-    uint64_t before = kFold ? fold_partial(tile_bits, tile) : 0, unused = 0;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     // 252 own block-channels + the first MCU of the next tile (threads 252..254)
     const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
@@ -286,27 +259,16 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     uint32_t tile_total;
     const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, tile_total);  // has barriers
 
-    uint64_t base_bits, end_bits;
-    if (kFold) {
-        fold_reduce(before, unused, lsum);
-        base_bits = before;
-        end_bits = base_bits + tile_bits[tile];
-    } else {
-        const uint64_t* tb = tile_base + (size_t)img * n_tiles;
-        base_bits = tb[tile];
-        end_bits = (tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1];
-    }
+    const uint64_t* tb = tile_base + (size_t)img * n_tiles;
+    uint64_t base_bits = tb[tile];
+    uint64_t end_bits = (tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1];
     base_bits += st.bit_base;  // image-stream coordinates
     end_bits += st.bit_base;
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1)
     const uint64_t d0 = base_bits >> 5;                      // image-relative dword of window word 0
     const uint32_t rel_start = (uint32_t)(base_bits & 31) + local_off;
     const uint32_t n_words = (uint32_t)((b1 * 8 - d0 * 32 + 31) >> 5);  // words that hold owned bytes
-    const uint64_t ubase = kFold ? 0 : img_ubase[img];
-    if (kFold && ((b1 + 3) & ~3ull) > unstuffed_capacity) {  // single image: no scan kernel has checked this
-        if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
-        return;
-    }
+    const uint64_t ubase = img_ubase[img];   // the scans have checked the capacity
     uint8_t* dst = unstuffed + ubase - st.origin_byte;  // indexed by image-stream byte
 
     // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
@@ -358,7 +320,6 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     if (threadIdx.x == 0) tile_ff[(size_t)img * n_tiles + tile] = ff_count;
 }
 
-template <bool kFold>
 __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, const uint32_t* __restrict__ tile_bits,
                                                             const uint64_t* __restrict__ tile_base,
                                                             const uint64_t* __restrict__ img_bits,
@@ -373,54 +334,25 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
                                                             uint8_t* __restrict__ out, uint64_t out_capacity,
                                                             int32_t* __restrict__ status, StripeInfo st) {
     __shared__ uint32_t wsum[4];
-    __shared__ uint64_t lsum[8];
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
-    const int32_t status_now = *status;
-    uint64_t bits_before = kFold ? fold_partial(tile_bits, tile) : 0;
-    uint64_t ff_fold = kFold ? fold_partial(tile_ff, tile) : 0;
-    if (status_now != 0) return;
-    uint64_t base_bits, end_bits;
-    if (kFold) {
-        fold_reduce(bits_before, ff_fold, lsum);
-        base_bits = bits_before;
-        end_bits = base_bits + tile_bits[tile];
-    } else {
-        const uint64_t* tb = tile_base + (size_t)img * n_tiles;
-        base_bits = tb[tile];
-        end_bits = (tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1];
-    }
-    base_bits += st.bit_base;
-    end_bits += st.bit_base;
+    if (*status != 0) return;
+    const uint64_t* tb = tile_base + (size_t)img * n_tiles;
+    const uint64_t base_bits = tb[tile] + st.bit_base;
+    const uint64_t end_bits = ((tile + 1 == n_tiles) ? img_bits[img] : tb[tile + 1]) + st.bit_base;
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;
-    uint64_t ff_before, file_offset;
-    if (kFold) {
-        ff_before = ff_fold;
-        file_offset = 0;
-        // the tile's last output byte (and, for the last tile, the EOI) must fit
+    const uint64_t ff_before = tile_ffbase[(size_t)img * n_tiles + tile];
+    const uint64_t file_offset = offsets[img];
+    if (st.active) {
+        // a stripe's segment: its owned bytes start at st.first_byte; exact size known here
         const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
-        if (header_len + b1 + ff_before + tile_ff[tile] + tail > out_capacity) {
+        if (header_len + (b1 - st.first_byte) + ff_before + tile_ff[(size_t)img * n_tiles + tile] + tail > out_capacity) {
             if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
             return;
         }
-        if (tile + 1 == n_tiles && threadIdx.x == 0) {
-            offsets[0] = 0;
-            sizes[0] = header_len + b1 + ff_before + tile_ff[tile] + tail;
-        }
-    } else {
-        ff_before = tile_ffbase[(size_t)img * n_tiles + tile];
-        file_offset = offsets[img];
-        if (st.active) {
-            // a stripe's segment: its owned bytes start at st.first_byte; exact size known here
-            const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
-            if (header_len + (b1 - st.first_byte) + ff_before + tile_ff[(size_t)img * n_tiles + tile] + tail > out_capacity) {
-                if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
-                return;
-            }
-            if (tile + 1 == n_tiles && threadIdx.x == 0)
-                sizes[img] = header_len + (b1 - st.first_byte) + img_ff[img] + tail;
-        }
+        if (tile + 1 == n_tiles && threadIdx.x == 0)
+            sizes[img] = header_len + (b1 - st.first_byte) + img_ff[img] + tail;
     }
-    const uint8_t* src = unstuffed + (kFold ? 0 : img_ubase[img]) - st.origin_byte;  // indexed by image-stream byte
+    const uint8_t* src = unstuffed + img_ubase[img] - st.origin_byte;  // indexed by image-stream byte
     uint8_t* file = out + file_offset;
     // + image-stream byte index + 0xFFs before it inside the tile
     uint8_t* dst = file + header_len + ff_before - st.first_byte;
@@ -428,8 +360,7 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
     if (tile == 0)
         for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) file[i] = header.b[i];
     if (tile + 1 == n_tiles && with_eoi && threadIdx.x == 0) {
-        const uint64_t ff_total = kFold ? ff_before + tile_ff[tile] : img_ff[img];
-        uint8_t* e = file + header_len + (b1 - st.first_byte) + ff_total;
+        uint8_t* e = file + header_len + (b1 - st.first_byte) + img_ff[img];
         e[0] = 0xFF;
         e[1] = 0xD9;
     }
@@ -461,12 +392,12 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
 }
 
 // ---------------------------------------------------------------------------
-// One image, two launches instead of three.  Where a tile's bytes go in the file depends on the 0xFF bytes
-// before it, and which bytes are 0xFF depends on how the tile's bits fall on the byte grid: on the bit
-// total of the tiles before it, modulo 8.  So the first kernel, besides the blocks' bit strings, lays the
-// tile's string out in LDS at bit offset 0 and counts, for each of the eight offsets the tile may end up at,
-// the 0xFF bytes it would own; the second kernel gets the 0xFF prefix from those counts while it sums the
-// bit totals, and stuffs straight out of its LDS window.  No unstuffed copy in memory, no third launch.
+// Two launches instead of three (plus scans).  Where a tile's bytes go in the file depends on the 0xFF bytes
+// before it, and which bytes are 0xFF depends on how the tile's bits fall on the byte grid: on the bit total
+// of the tiles before it, modulo 8.  So the first kernel, besides writing the blocks' bit strings, counts for
+// each of the eight offsets the tile may end up at the 0xFF bytes it would own; the second kernel (or the
+// scan in between) gets the 0xFF prefix from those counts along with the bit totals, and stuffs straight out
+// of its LDS window.  No unstuffed copy in memory.
 // ---------------------------------------------------------------------------
 
 // ORs every thread's string (my_len bits in slot words, starting `start` bits into the window's word 0 of
@@ -486,6 +417,7 @@ __device__ __forceinline__ void or_strings(uint32_t* win, const uint32_t* __rest
 
 template <bool kPlanar>
 __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+                                                                uint32_t n_tiles,
                                                                 const HuffTables* __restrict__ huff,
                                                                 const uint8_t* __restrict__ chunk_masks,
                                                                 ComponentMode mode, uint16_t* __restrict__ len16,
@@ -497,7 +429,7 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t count[8];
     __shared__ uint32_t lens[kEntThreads];
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     // 252 own block-channels, and the first MCU of the next tile once more (threads 252..254): the byte that
     // straddles two tiles belongs to the earlier one, whose 0xFF count needs those bits
@@ -508,12 +440,12 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
     if (has_block) {
         if (kPlanar) {
             const uint32_t n_mcu = nbc / 3u, mcu = b / 3u;
-            const uint4* q = reinterpret_cast<const uint4*>(coefs) + (size_t)ch * n_mcu + mcu;
-            load_block_planar(blk, q, (size_t)3 * n_mcu, (uint32_t)chunk_masks[b]);
+            const uint4* q = reinterpret_cast<const uint4*>(coefs) + ((size_t)img * 24 + ch) * n_mcu + mcu;
+            load_block_planar(blk, q, (size_t)3 * n_mcu, (uint32_t)chunk_masks[(size_t)img * nbc + b]);
             prev_dc = (b >= 3) ? (int)*reinterpret_cast<const int16_t*>(q - 1) : 0;
         } else {
-            const int16_t* p = coefs + (size_t)b * 64;
-            load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[b] : 0xffu);
+            const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
+            load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
             prev_dc = (b >= 3) ? (int)p[-192] : 0;
         }
     }
@@ -521,7 +453,7 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
     if (threadIdx.x < 8) count[threadIdx.x] = 0;
     __syncthreads();
 
-    uint32_t* const slot = slots + (size_t)tile * kSlotWords * kSlotStride + threadIdx.x;
+    uint32_t* const slot = slots + ((size_t)img * n_tiles + tile) * kSlotWords * kSlotStride + threadIdx.x;
     uint32_t my_len = 0;
     if (has_block) {
         const int cls = mode.is_lum((uint32_t)ch) ? 0 : 1;   // Huffman table class (encoder.cpp:25)
@@ -530,12 +462,12 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
         if (!encode_block(blk, prev_dc, h.dc[cls], h.ac[cls], sink)) atomicExch(status, JEA_ERR_RANGE);
         sink.finish();
         my_len = sink.bits;
-        if (threadIdx.x < kTileBlocks) len16[b] = (uint16_t)my_len;
+        if (threadIdx.x < kTileBlocks) len16[(size_t)img * nbc + b] = (uint16_t)my_len;
     }
     lens[threadIdx.x] = my_len;
     uint32_t with_next;
     const uint32_t local_off = block_exclusive_scan_256(my_len, wsum, with_next);   // has barriers
-    if (threadIdx.x == kTileBlocks) tile_bits[tile] = local_off;   // its prefix is the total of the tile's own blocks
+    if (threadIdx.x == kTileBlocks) tile_bits[(size_t)img * n_tiles + tile] = local_off;   // its prefix is the total of the tile's own blocks
 
     // Bit p of the tile's string starts a 0xFF byte for the alignments that put a byte boundary there, if bits
     // p .. p+7 are ones; the tile owns the bytes that start inside it.  Each thread reads its string back, with
@@ -581,7 +513,7 @@ __global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* _
     }
     __syncthreads();
     if (threadIdx.x == 0)   // eight 16-bit counts: a tile has at most 252 * 1660 / 8 bytes
-        tile_ff8[tile] = make_uint4(count[0] | count[1] << 16, count[2] | count[3] << 16, count[4] | count[5] << 16,
+        tile_ff8[(size_t)img * n_tiles + tile] = make_uint4(count[0] | count[1] << 16, count[2] | count[3] << 16, count[4] | count[5] << 16,
                                     count[6] | count[7] << 16);
 }
 
@@ -593,108 +525,199 @@ __device__ __forceinline__ uint32_t ff_at(const uint4& f, uint32_t base_bits) {
     return (uint32_t)(((r & 4u) ? hi : lo) >> (16u * (r & 3u))) & 0xffffu;
 }
 
+// One workgroup per image.  Exclusive scan of the tiles' bit totals; each tile's bit base picks its 0xFF count
+// out of the eight, and those are scanned in the same pass.  A single image's offset and size are final here.
+__global__ __launch_bounds__(1024) void scan_tiles_ff_kernel(const uint32_t* __restrict__ tile_bits,
+                                                             const uint4* __restrict__ tile_ff8, uint32_t n_tiles,
+                                                             uint64_t* __restrict__ tile_base,
+                                                             uint64_t* __restrict__ tile_ffbase,
+                                                             uint64_t* __restrict__ img_bits,
+                                                             uint64_t* __restrict__ img_ff, ImageLevel lvl) {
+    __shared__ uint64_t wave_bits[16], wave_ff[16];
+    __shared__ uint64_t carry_bits, carry_ff;
+    const uint32_t img = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_bits = carry_ff = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const size_t at = (size_t)img * n_tiles + t;
+        const uint64_t v = (t < n_tiles) ? (uint64_t)tile_bits[at] : 0;
+        const uint4 f = (t < n_tiles) ? tile_ff8[at] : make_uint4(0, 0, 0, 0);
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t u = __shfl_up(incl, d);
+            if (lane >= d) incl += u;
+        }
+        if (lane == 63) wave_bits[wave] = incl;
+        __syncthreads();
+        uint64_t base = carry_bits;
+        for (int w = 0; w < wave; ++w) base += wave_bits[w];
+        const uint64_t bit_base = base + incl - v;
+        const uint64_t ff = (t < n_tiles) ? ff_at(f, (uint32_t)bit_base) : 0;
+        uint64_t incl_ff = ff;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t u = __shfl_up(incl_ff, d);
+            if (lane >= d) incl_ff += u;
+        }
+        if (lane == 63) wave_ff[wave] = incl_ff;
+        __syncthreads();
+        uint64_t base_ff = carry_ff;
+        for (int w = 0; w < wave; ++w) base_ff += wave_ff[w];
+        if (t < n_tiles) {
+            tile_base[at] = bit_base;
+            tile_ffbase[at] = base_ff + incl_ff - ff;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            carry_bits = base + incl;
+            carry_ff = base_ff + incl_ff;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        img_bits[img] = carry_bits;
+        img_ff[img] = carry_ff;
+        if (gridDim.x == 1) {
+            const uint64_t size = unstuffed_bytes(carry_bits) + carry_ff + lvl.fixed_bytes;
+            lvl.base_out[0] = 0;
+            lvl.size_out[0] = size;
+            if (size > lvl.capacity) atomicExch(lvl.status, JEA_ERR_CAPACITY);
+        }
+    }
+}
+
+// kFold: one image of at most kFoldTiles tiles, every workgroup works out the sums over the tiles before it.
+// Otherwise the sums come from scan_tiles_ff_kernel (and scan_images_kernel), which have also written the
+// files' offsets and sizes and checked the capacity.
+template <bool kFold>
 __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc, uint32_t n_tiles,
-                                                                 const uint32_t* __restrict__ slots,
-                                                                 const uint16_t* __restrict__ len16,
-                                                                 const uint32_t* __restrict__ tile_bits,
-                                                                 const uint4* __restrict__ tile_ff8,
-                                                                 uint64_t* __restrict__ offsets,
-                                                                 uint64_t* __restrict__ sizes, HeaderBytes header,
-                                                                 uint32_t header_len, uint32_t with_eoi,
-                                                                 uint8_t* __restrict__ out, uint64_t out_capacity,
-                                                                 int32_t* __restrict__ status) {
+                                                                    const uint32_t* __restrict__ slots,
+                                                                    const uint16_t* __restrict__ len16,
+                                                                    const uint32_t* __restrict__ tile_bits,
+                                                                    const uint4* __restrict__ tile_ff8,
+                                                                    const uint64_t* __restrict__ tile_base,
+                                                                    const uint64_t* __restrict__ tile_ffbase,
+                                                                    uint64_t* __restrict__ offsets,
+                                                                    uint64_t* __restrict__ sizes, HeaderBytes header,
+                                                                    uint32_t header_len, uint32_t with_eoi,
+                                                                    uint8_t* __restrict__ out, uint64_t out_capacity,
+                                                                    int32_t* __restrict__ status) {
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4], psum[8], fsum[4];
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const int32_t status_now = *status;
-    // Tiles before this one, a contiguous run of them per thread: their bit totals give the bit base of each
-    // (after one scan over the threads), its alignment, and with that its 0xFF count.
-    const uint32_t per_thread = (tile + kEntThreads - 1) / kEntThreads;
-    const uint32_t j0 = threadIdx.x * per_thread, j1 = (j0 + per_thread < tile) ? j0 + per_thread : tile;
-    // Up to kRun tiles per thread (any picture up to 1536 tiles, a 4K one has 1286): everything is loaded
-    // before the scan, all eight counts of each tile, so that no load waits for the scan's result.
-    constexpr uint32_t kRun = 6;
-    const bool short_run = per_thread <= kRun;
-    uint32_t run_bits = 0, rb[kRun];
-    uint4 rf[kRun];
-    if (short_run) {
-#pragma unroll
-        for (uint32_t u = 0; u < kRun; ++u) {
-            const bool in = j0 + u < j1;
-            rb[u] = in ? tile_bits[j0 + u] : 0u;
-            rf[u] = in ? tile_ff8[j0 + u] : make_uint4(0, 0, 0, 0);
-            run_bits += rb[u];
-        }
-    } else {
-        for (uint32_t j = j0; j < j1; ++j) run_bits += tile_bits[j];
-    }
-    const uint32_t own_bits = tile_bits[tile];
-    const uint4 own_ff8 = tile_ff8[tile];
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
-    const uint32_t my_len = has_block ? len16[b] : 0u;
-    if (status_now != 0) return;
-    // one scan for both: the runs' bit totals (a) and the lengths of this tile's strings (b)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl_a = run_bits, incl_b = my_len;
+    uint64_t base_bits, ff_before;
+    uint32_t own_bits, own_ff, my_len, local_off;
+    if (kFold) {
+        // Tiles before this one, a contiguous run of them per thread: their bit totals give the bit base of each
+        // (after one scan over the threads), its alignment, and with that its 0xFF count.
+        const uint32_t per_thread = (tile + kEntThreads - 1) / kEntThreads;
+        const uint32_t j0 = threadIdx.x * per_thread, j1 = (j0 + per_thread < tile) ? j0 + per_thread : tile;
+        // Up to kRun tiles per thread (any picture up to 1536 tiles, a 4K one has 1286): everything is loaded
+        // before the scan, all eight counts of each tile, so that no load waits for the scan's result.
+        constexpr uint32_t kRun = 6;
+        const bool short_run = per_thread <= kRun;
+        uint32_t run_bits = 0, rb[kRun];
+        uint4 rf[kRun];
+        if (short_run) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t ta = __shfl_up(incl_a, d), tb = __shfl_up(incl_b, d);
-        if (lane >= d) {
-            incl_a += ta;
-            incl_b += tb;
+            for (uint32_t u = 0; u < kRun; ++u) {
+                const bool in = j0 + u < j1;
+                rb[u] = in ? tile_bits[j0 + u] : 0u;
+                rf[u] = in ? tile_ff8[j0 + u] : make_uint4(0, 0, 0, 0);
+                run_bits += rb[u];
+            }
+        } else {
+            for (uint32_t j = j0; j < j1; ++j) run_bits += tile_bits[j];
         }
-    }
-    if (lane == 63) {
-        psum[wave] = incl_a;
-        psum[4 + wave] = incl_b;
-    }
-    __syncthreads();
-    uint32_t base_a = 0, base_b = 0, bits_before = 0;   // fits: at most 4096 tiles of 252 * 1660 bits
+        own_bits = tile_bits[tile];
+        const uint4 own_ff8 = tile_ff8[tile];
+        my_len = has_block ? len16[b] : 0u;
+        if (status_now != 0) return;
+        // one scan for both: the runs' bit totals (a) and the lengths of this tile's strings (b)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t incl_a = run_bits, incl_b = my_len;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) {
-            base_a += psum[w];
-            base_b += psum[4 + w];
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ta = __shfl_up(incl_a, d), tb = __shfl_up(incl_b, d);
+            if (lane >= d) {
+                incl_a += ta;
+                incl_b += tb;
+            }
         }
-        bits_before += psum[w];
-    }
-    uint32_t running = base_a + incl_a - run_bits;
-    const uint32_t local_off = base_b + incl_b - my_len;
-    uint32_t ff_run = 0;
-    if (short_run) {
+        if (lane == 63) {
+            psum[wave] = incl_a;
+            psum[4 + wave] = incl_b;
+        }
+        __syncthreads();
+        uint32_t base_a = 0, base_b = 0, bits_before = 0;   // fits: at most 4096 tiles of 252 * 1660 bits
 #pragma unroll
-        for (uint32_t u = 0; u < kRun; ++u) {
-            ff_run += ff_at(rf[u], running);
-            running += rb[u];
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) {
+                base_a += psum[w];
+                base_b += psum[4 + w];
+            }
+            bits_before += psum[w];
+        }
+        uint32_t running = base_a + incl_a - run_bits;
+        local_off = base_b + incl_b - my_len;
+        uint32_t ff_run = 0;
+        if (short_run) {
+#pragma unroll
+            for (uint32_t u = 0; u < kRun; ++u) {
+                ff_run += ff_at(rf[u], running);
+                running += rb[u];
+            }
+        } else {
+            for (uint32_t j = j0; j < j1; ++j) {
+                ff_run += ff_at(tile_ff8[j], running);
+                running += tile_bits[j];
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ff_run += __shfl_xor(ff_run, d);
+        if (lane == 0) fsum[wave] = ff_run;
+        __syncthreads();
+        ff_before = (uint64_t)fsum[0] + fsum[1] + fsum[2] + fsum[3];
+        base_bits = bits_before;
+        own_ff = ff_at(own_ff8, bits_before);
+    } else {
+        const size_t t = (size_t)img * n_tiles + tile;
+        base_bits = tile_base[t];
+        ff_before = tile_ffbase[t];
+        own_bits = tile_bits[t];
+        const uint4 own_ff8 = tile_ff8[t];
+        my_len = has_block ? len16[(size_t)img * nbc + b] : 0u;
+        if (status_now != 0) return;
+        uint32_t tile_total;
+        local_off = block_exclusive_scan_256(my_len, wsum, tile_total);
+        own_ff = ff_at(own_ff8, (uint32_t)base_bits);
+    }
+    const uint64_t end_bits = base_bits + own_bits;
+    const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1) of the unstuffed stream
+    uint8_t* file = out;
+    if (kFold) {
+        const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
+        if (header_len + b1 + ff_before + own_ff + tail > out_capacity) {
+            if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
+            return;
+        }
+        if (tile + 1 == n_tiles && threadIdx.x == 0) {
+            offsets[0] = 0;
+            sizes[0] = header_len + b1 + ff_before + own_ff + tail;
         }
     } else {
-        for (uint32_t j = j0; j < j1; ++j) {
-            ff_run += ff_at(tile_ff8[j], running);
-            running += tile_bits[j];
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) ff_run += __shfl_xor(ff_run, d);
-    if (lane == 0) fsum[wave] = ff_run;
-    __syncthreads();
-    const uint64_t ff_before = (uint64_t)fsum[0] + fsum[1] + fsum[2] + fsum[3];
-    const uint64_t base_bits = bits_before, end_bits = base_bits + own_bits;
-    const uint32_t own_ff = ff_at(own_ff8, bits_before);
-    const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1) of the unstuffed stream
-    const uint64_t tail = (tile + 1 == n_tiles && with_eoi) ? 2 : 0;
-    if (header_len + b1 + ff_before + own_ff + tail > out_capacity) {
-        if (threadIdx.x == 0) atomicExch(status, JEA_ERR_CAPACITY);
-        return;
-    }
-    if (tile + 1 == n_tiles && threadIdx.x == 0) {
-        offsets[0] = 0;
-        sizes[0] = header_len + b1 + ff_before + own_ff + tail;
+        file += offsets[img];
     }
     if (tile == 0)
-        for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) out[i] = header.b[i];
+        for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) file[i] = header.b[i];
     if (tile + 1 == n_tiles && with_eoi && threadIdx.x == 0) {
-        uint8_t* e = out + header_len + b1 + ff_before + own_ff;
+        uint8_t* e = file + header_len + b1 + ff_before + own_ff;
         e[0] = 0xFF;
         e[1] = 0xD9;
     }
@@ -705,8 +728,8 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
     // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
     const uint32_t slot_tile = threadIdx.x < kTileBlocks ? tile : tile + 1;
     const uint32_t slot_col = threadIdx.x < kTileBlocks ? threadIdx.x : threadIdx.x - kTileBlocks;
-    const uint32_t* slot = slots + (size_t)slot_tile * kSlotWords * kSlotStride + slot_col;
-    uint8_t* const dst = out + header_len + ff_before;       // + stream byte index + 0xFFs of this tile before it
+    const uint32_t* slot = slots + ((size_t)img * n_tiles + slot_tile) * kSlotWords * kSlotStride + slot_col;
+    uint8_t* const dst = file + header_len + ff_before;      // + stream byte index + 0xFFs of this tile before it
     uint64_t carry = 0;
     for (uint32_t wlo = 0; wlo < n_words; wlo += kWinWords) {
         const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
@@ -770,57 +793,61 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const uint32_t n = (uint32_t)n_images;
     const uint32_t eoi = with_eoi ? 1u : 0u;
 
-    if (n == 1 && n_tiles <= kFoldTiles) {
+    // Many tiles: throughput counts, and the 0xFF tally for all eight alignments costs the bit-length kernel a
+    // little more than a stuffing pass of its own costs (9.8 against 10.1 ms for 1024 frames of 1920x1080 at
+    // quality 90): bit lengths, scans, pack into an unstuffed copy, scans of its 0xFF counts, stuff.
+    if ((uint64_t)n * n_tiles > kLatencyTiles) {
         if (sc.planar)
-            tile_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, d_huff, sc.chunk_masks, sc.mode, sc.len16,
-                                                                sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8, d_status);
+            block_bits_kernel<true, true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
+                                                                       sc.slots, d_status, StripeInfo{}, sc.chunk_masks,
+                                                                       sc.mode);
         else
-            tile_bits_kernel<false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, d_huff, sc.chunk_masks, sc.mode, sc.len16,
-                                                                 sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8, d_status);
-        pack_stuff_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, (const uint4*)sc.tile_ff8,
-                                                       d_offsets, d_sizes, header, (uint32_t)header_len, eoi, d_out,
-                                                       out_capacity, d_status);
+            block_bits_kernel<true, false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16,
+                                                                        sc.tile_bits, sc.slots, d_status, StripeInfo{},
+                                                                        sc.chunk_masks, sc.mode);
+        ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
+        scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
+        if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_bits, l1);
+        pack_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
+                                                 sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
+                                                 sc.tile_ff, d_status, StripeInfo{});
+        ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
+        scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
+        if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, l2);
+        stuff_kernel<<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
+                                                  sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets, d_sizes,
+                                                  header, (uint32_t)header_len, eoi, d_out, out_capacity, d_status,
+                                                  StripeInfo{});
         return;
     }
 
+    // Few tiles: the launches' latencies count.  The bit-length kernel also tallies the 0xFF bytes; one kernel
+    // packs and stuffs.
     if (sc.planar)
-        block_bits_kernel<true, true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                                   sc.slots, d_status, StripeInfo{}, sc.chunk_masks,
-                                                                   sc.mode);
+        tile_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.chunk_masks, sc.mode,
+                                                            sc.len16, sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8,
+                                                            d_status);
     else
-        block_bits_kernel<true, false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16,
-                                                                    sc.tile_bits, sc.slots, d_status, StripeInfo{},
-                                                                    sc.chunk_masks, sc.mode);
-
+        tile_bits_kernel<false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.chunk_masks, sc.mode,
+                                                             sc.len16, sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8,
+                                                             d_status);
     if (n == 1 && n_tiles <= kFoldTiles) {
-        // One image with few tiles: every workgroup sums the totals of the tiles
-        // before it, which is cheaper than two dependent single-workgroup scans.
-        pack_kernel<true><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, nullptr, nullptr,
-                                                       nullptr, sc.unstuffed, sc.unstuffed_capacity, sc.tile_ff,
-                                                       d_status, StripeInfo{});
-        stuff_kernel<true><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, nullptr, nullptr, nullptr, sc.unstuffed,
-                                                        sc.tile_ff, nullptr, nullptr, d_offsets, d_sizes, header,
-                                                        (uint32_t)header_len, eoi, d_out, out_capacity, d_status,
-                                                        StripeInfo{});
+        // One image with few tiles: every workgroup sums over the tiles before it, which is cheaper than a
+        // single-workgroup scan launched in between.
+        pack_stuff_kernel<true><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits,
+                                                             (const uint4*)sc.tile_ff8, nullptr, nullptr, d_offsets,
+                                                             d_sizes, header, (uint32_t)header_len, eoi, d_out,
+                                                             out_capacity, d_status);
         return;
     }
-
-    ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
-    scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
-    if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_bits, l1);
-
-    pack_kernel<false><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
-                                                    sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
-                                                    sc.tile_ff, d_status, StripeInfo{});
-
-    ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
-    scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
-    if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, l2);
-
-    stuff_kernel<false><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
-                                                     sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets,
-                                                     d_sizes, header, (uint32_t)header_len, eoi, d_out, out_capacity,
-                                                     d_status, StripeInfo{});
+    ImageLevel lvl{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
+    scan_tiles_ff_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, (const uint4*)sc.tile_ff8, n_tiles, sc.tile_base,
+                                            sc.tile_ffbase, sc.img_bits, sc.img_ff, lvl);
+    if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, lvl);
+    pack_stuff_kernel<false><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits,
+                                                          (const uint4*)sc.tile_ff8, sc.tile_base, sc.tile_ffbase,
+                                                          d_offsets, d_sizes, header, (uint32_t)header_len, eoi, d_out,
+                                                          out_capacity, d_status);
 }
 
 namespace {
@@ -859,13 +886,13 @@ void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, 
     const uint32_t n_tiles = tiles_per_image(mcus);
     const dim3 grid(n_tiles, 1);
     const uint32_t eoi = with_eoi ? 1u : 0u;
-    pack_kernel<false><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
+    pack_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
                                                     sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
                                                     sc.tile_ff, d_status, st);
     // the scan's own size estimate is only a capacity check here; the stuff pass writes the exact segment size
     ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity + 8, (uint32_t)header_len + 2 * eoi, d_status};
     scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
-    stuff_kernel<false><<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
+    stuff_kernel<<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
                                                      sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets,
                                                      d_sizes, header, (uint32_t)header_len, eoi, d_out, out_capacity,
                                                      d_status, st);

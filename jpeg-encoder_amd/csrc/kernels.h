@@ -135,7 +135,8 @@ struct EntropyScratch {
     uint64_t* img_ff;       // [n]
     uint8_t* unstuffed;     // packed, not yet byte-stuffed streams
     size_t unstuffed_capacity;
-    uint32_t* tile_ff8;     // [n_tiles][8]  single images: 0xFF bytes a tile owns, for each alignment of the tile
+    uint32_t* tile_ff8;     // [n_images][n_tiles] x 16 bytes: 0xFF bytes a tile owns for each of the eight bit
+                            // alignments it may get, as 16-bit counts
 };
 
 // d_status_to_clear (may be null): status word of the encode pass this launch opens; the kernel zeroes it.

@@ -191,6 +191,47 @@ def test_encode_batch_of_images(ctx, po, jea):
         assert off[i] >= off[i - 1] + size[i - 1]
 
 
+def test_encode_batch_of_noise_at_full_quality(ctx, po, jea):
+    """Batches whose streams are full of 0xFF bytes: where a tile's bytes go depends on the 0xFF bytes of the
+    tiles before it, and which of its bytes are 0xFF on the bit offset it starts at."""
+    w, h, quality, n = 136, 104, 100, 5
+    lum, chrom = jea.binding.quant_tables(quality)
+    imgs = [po.gen_image(w, h, 1, 700 + i) for i in range(n)]
+    imgs[2] = np.full((h, w, 3), 255, np.uint8)
+    imgs[2][::3, ::5] = 0
+    out, off, size = ctx.encode_batch(ctx.to_device(np.stack(imgs).reshape(-1)), n, w, h, lum, chrom)
+    host = out.cpu().numpy()
+    for i in range(n):
+        want = po.encode(imgs[i], quality)
+        assert host[int(off[i]): int(off[i] + size[i])].tobytes() == want, i
+        assert want[607:-2].count(b"\xff") > 5 or i == 2
+
+
+def test_encode_batch_with_more_tiles_than_the_short_path_takes(ctx, po, jea):
+    """Launches of more than 32768 tiles take the path with a stuffing pass of its own: 33000 pictures of 8x8."""
+    w = h = 8
+    quality, n = 90, 33000
+    lum, chrom = jea.binding.quant_tables(quality)
+    kinds = [po.gen_image(w, h, 1, 40 + i) for i in range(5)] + [np.full((h, w, 3), 255, np.uint8)]
+    want = [po.encode(k, quality) for k in kinds]
+    batch = np.stack([kinds[i % len(kinds)] for i in range(n)])
+    out, off, size = ctx.encode_batch(ctx.to_device(batch.reshape(-1)), n, w, h, lum, chrom)
+    host = out.cpu().numpy()
+    for i in list(range(0, n, 997)) + list(range(n - 8, n)):
+        assert host[int(off[i]): int(off[i] + size[i])].tobytes() == want[i % len(kinds)], i
+    assert np.array_equal(size, np.array([len(want[i % len(kinds)]) for i in range(n)], dtype=size.dtype))
+
+
+def test_encode_single_image_of_more_tiles_than_a_workgroup_sums(ctx, po, jea):
+    """A picture of more than 4096 tiles: the sums over the tiles come from the scan kernel."""
+    w, h, quality = 6000, 4000, 75
+    lum, chrom = jea.binding.quant_tables(quality)
+    rgb = po.gen_image(w, h, 0, 77)
+    rgb[1000:1400, 2000:2600] = po.gen_image(600, 400, 1, 78)
+    out, off, size = ctx.encode_batch(ctx.to_device(rgb.reshape(-1)), 1, w, h, lum, chrom, capacity=64 << 20)
+    assert out.cpu().numpy()[: int(size[0])].tobytes() == po.encode(rgb, quality)
+
+
 def test_golden_hashes(ctx, po, jea):
     """The whole-file hashes recorded from the reference itself (tests/golden/reference_hashes.json)."""
     rows = json.load(open(os.path.join(GOLDEN, "reference_hashes.json")))["rows"]
