@@ -1,8 +1,9 @@
 """Time the GPU decode (entropy decode + inverse transform) of device-resident files."""
-import importlib, sys, time
+import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
-sys.path.insert(0, "oracle")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 jea = importlib.import_module("jpeg-encoder_amd")
 import pyoracle as po
 import torch
