@@ -191,6 +191,29 @@ def test_encode_batch_of_images(ctx, po, jea):
         assert off[i] >= off[i - 1] + size[i - 1]
 
 
+@pytest.mark.parametrize("n,w,h", [(1, 256, 256), (6, 200, 120), (1, 6000, 4000), (33000, 8, 8)])
+def test_encode_capacity_error_on_every_path(ctx, po, jea, n, w, h):
+    """An output buffer a little too small for the last file: capacity error, nothing written past the buffer,
+    and the context keeps working.  One case for each way the coder lays out its launches."""
+    quality = 90
+    lum, chrom = jea.binding.quant_tables(quality)
+    rgb = po.gen_image(w, h, 1 if w * h < 1 << 20 else 0, 5)
+    d_rgb = ctx.to_device(np.tile(rgb.reshape(-1), n))
+    out, off, size = ctx.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=64 << 20)
+    need = int(off[n - 1] + size[n - 1])
+    guard = 4096
+    buf = ctx.torch.full((need + guard,), 0x5a, dtype=ctx.torch.uint8, device=ctx.tdev)
+    with pytest.raises(jea.JeaError) as e:
+        ctx.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=need - 1, d_out=buf)
+    assert e.value.code == 3
+    assert bool((buf[need - 1:] == 0x5a).all())
+    out2, off2, size2 = ctx.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=need, d_out=buf)
+    assert np.array_equal(size2, size) and np.array_equal(off2, off)
+    for i in sorted({0, n // 2, n - 1}):   # the gaps between files (64-byte steps) are nobody's
+        a, b = int(off[i]), int(off[i] + size[i])
+        assert ctx.torch.equal(buf[a:b], out[a:b]), i
+
+
 def test_encode_batch_of_noise_at_full_quality(ctx, po, jea):
     """Batches whose streams are full of 0xFF bytes: where a tile's bytes go depends on the 0xFF bytes of the
     tiles before it, and which of its bytes are 0xFF on the bit offset it starts at."""
