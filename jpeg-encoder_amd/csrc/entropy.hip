@@ -589,6 +589,46 @@ __global__ __launch_bounds__(1024) void scan_tiles_ff_kernel(const uint32_t* __r
     }
 }
 
+// Stuffs the owned bytes [b0, b1) that lie in a window of the packed stream (win[0 .. words_here), its first
+// byte is stream byte win_byte) to dst + stream byte index + 0xFFs of this tile before it: bit_stream.cpp:127-134
+// (intended semantics) as count -> scan over the workgroup -> scatter, kWords words per thread and step.
+// Short windows (a tile of a smooth picture has about a hundred words) take one word per thread, so that the
+// step's instructions are not spent on threads without bytes.
+template <uint32_t kWords>
+__device__ __forceinline__ void stuff_window(const uint32_t* win, uint32_t words_here, uint64_t win_byte, uint64_t b0,
+                                             uint64_t b1, uint8_t* dst, uint64_t& carry, uint32_t* wsum) {
+    for (uint32_t w0 = 0; w0 < words_here; w0 += kEntThreads * kWords) {
+        const uint32_t wi = w0 + threadIdx.x * kWords;
+        uint32_t bytes[4 * kWords];
+        uint32_t owned = 0, cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4 * kWords; ++k) {
+            const uint32_t word = wi + (k >> 2);
+            const uint64_t x = win_byte + (uint64_t)word * 4 + (k & 3);      // stream byte index
+            const uint32_t v = word < words_here ? win[word] : 0u;
+            bytes[k] = (v >> (24 - 8 * (k & 3))) & 0xffu;
+            if (word < words_here && x >= b0 && x < b1) {
+                owned |= 1u << k;
+                cnt += bytes[k] == 0xffu;
+            }
+        }
+        uint32_t total;
+        uint32_t pos = block_exclusive_scan_256(cnt, wsum, total);
+        uint8_t* const to = dst + (win_byte + (uint64_t)wi * 4 + carry);
+#pragma unroll
+        for (uint32_t k = 0; k < 4 * kWords; ++k) {
+            if ((owned >> k) & 1u) {
+                to[k + pos] = (uint8_t)bytes[k];
+                if (bytes[k] == 0xffu) {
+                    ++pos;
+                    to[k + pos] = 0x00;
+                }
+            }
+        }
+        carry += total;   // the scan's last barrier is also what lets the next window be cleared
+    }
+}
+
 // kFold: one image of at most kFoldTiles tiles, every workgroup works out the sums over the tiles before it.
 // Otherwise the sums come from scan_tiles_ff_kernel (and scan_images_kernel), which have also written the
 // files' offsets and sizes and checked the capacity.
@@ -714,8 +754,15 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
     } else {
         file += offsets[img];
     }
-    if (tile == 0)
-        for (uint32_t i = threadIdx.x; i < header_len; i += kEntThreads) file[i] = header.b[i];
+    if (tile == 0) {
+        // three fixed steps cover the 608 bytes; as a loop over header_len the compiler unrolls it eightfold, and
+        // this code, which one workgroup runs, pushes the kernel over its register limit
+#pragma unroll
+        for (uint32_t r = 0; r < (sizeof(header.b) + kEntThreads - 1) / kEntThreads; ++r) {
+            const uint32_t i = r * kEntThreads + threadIdx.x;
+            if (i < header_len) file[i] = header.b[i < sizeof(header.b) ? i : 0];
+        }
+    }
     if (tile + 1 == n_tiles && with_eoi && threadIdx.x == 0) {
         uint8_t* e = file + header_len + b1 + ff_before + own_ff;
         e[0] = 0xFF;
@@ -737,38 +784,10 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
         __syncthreads();
         or_strings(win, slot, my_len, rel_start, wlo);
         __syncthreads();
-        // sixteen bytes (four words) per thread and step, bit_stream.cpp:127-134 (intended semantics)
-        for (uint32_t w0 = 0; w0 < words_here; w0 += kEntThreads * 4) {
-            const uint32_t wi = w0 + threadIdx.x * 4;
-            uint32_t bytes[16];
-            uint32_t owned = 0, cnt = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) {
-                const uint32_t word = wi + (k >> 2);
-                const uint64_t x = (d0 + wlo + word) * 4 + (k & 3);      // stream byte index
-                const uint32_t v = word < words_here ? win[word] : 0u;
-                bytes[k] = (v >> (24 - 8 * (k & 3))) & 0xffu;
-                if (word < words_here && x >= b0 && x < b1) {
-                    owned |= 1u << k;
-                    cnt += bytes[k] == 0xffu;
-                }
-            }
-            uint32_t total;
-            uint64_t pos = carry + block_exclusive_scan_256(cnt, wsum, total);
-            const uint64_t x0 = (d0 + wlo + wi) * 4;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) {
-                if ((owned >> k) & 1u) {
-                    dst[x0 + k + pos] = (uint8_t)bytes[k];
-                    if (bytes[k] == 0xffu) {
-                        ++pos;
-                        dst[x0 + k + pos] = 0x00;
-                    }
-                }
-            }
-            carry += total;
-        }
-        __syncthreads();
+        if (words_here <= kEntThreads)
+            stuff_window<1>(win, words_here, (d0 + wlo) * 4, b0, b1, dst, carry, wsum);
+        else
+            stuff_window<4>(win, words_here, (d0 + wlo) * 4, b0, b1, dst, carry, wsum);
     }
 }
 
