@@ -285,7 +285,9 @@ bool tables_ok(const uint16_t lum_q[64], const uint16_t chr_q[64]) {
 }
 
 // Scratch of one entropy-encode pass.
-int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t out_capacity, EntropyScratch& sc) {
+// `for_stripe`: stripes pack into an unstuffed copy first (their bit offsets come from other contexts).
+int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t out_capacity, EntropyScratch& sc,
+                            bool for_stripe = false) {
     const size_t nbc = mcus * 3, n_tiles = tiles_per_image(mcus);
     int rc;
     if ((rc = ensure(ctx, ctx->len16, n_images * nbc * sizeof(uint16_t)))) return rc;
@@ -293,14 +295,17 @@ int prepare_entropy_scratch(jea_ctx* ctx, size_t n_images, size_t mcus, size_t o
         return rc;
     if ((rc = ensure(ctx, ctx->tile_bits, n_images * n_tiles * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->tile_base, n_images * n_tiles * sizeof(uint64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->tile_ff, n_images * n_tiles * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->tile_ffbase, n_images * n_tiles * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->img_words, 3 * n_images * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->tile_ff8, n_images * n_tiles * 4 * sizeof(uint32_t)))) return rc;
-    // The packed stream of an image is never longer than its stuffed one.
-    const size_t worst = n_images * ((nbc * 1660 + 7) / 8 + 16);
-    const size_t ucap = (out_capacity + 16 * n_images < worst) ? out_capacity + 16 * n_images : worst;
-    if ((rc = ensure(ctx, ctx->unstuffed, ucap))) return rc;
+    size_t ucap = 0;
+    if (for_stripe) {
+        // The packed stream of an image is never longer than its stuffed one.
+        const size_t worst = n_images * ((nbc * 1660 + 7) / 8 + 16);
+        ucap = (out_capacity + 16 * n_images < worst) ? out_capacity + 16 * n_images : worst;
+        if ((rc = ensure(ctx, ctx->unstuffed, ucap))) return rc;
+        if ((rc = ensure(ctx, ctx->tile_ff, n_images * n_tiles * sizeof(uint32_t)))) return rc;
+    }
     sc.len16 = (uint16_t*)ctx->len16.ptr;
     sc.chunk_masks = nullptr;  // set by callers whose coefficients come with masks from the forward kernel
     sc.planar = false;
@@ -823,7 +828,7 @@ int jea_stripe_transform(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t wid
     // worst-case scratch for the later steps, so that they never reallocate between launches
     EntropyScratch sc;
     const size_t worst = (mcus * 3 * 1660 + 7) / 8 + 64;
-    if ((rc = prepare_entropy_scratch(ctx, 1, mcus, worst, sc))) return rc;
+    if ((rc = prepare_entropy_scratch(ctx, 1, mcus, worst, sc, true))) return rc;
     int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
     launch_fdct_quant(ctx->stream, d_rgb_stripe, 1, width, stripe_height, to_float_tables(lum_q, chr_q), d_coefs,
                       ctx->d_status, (uint8_t*)ctx->masks.ptr, false, ctx->mode);
@@ -846,7 +851,7 @@ int jea_stripe_bits(jea_ctx* ctx, const int16_t prev_dc[3], uint64_t* total_bits
     JEA_HIP(ctx, hipSetDevice(ctx->device));
     EntropyScratch sc;
     int rc;
-    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc))) return rc;
+    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc, true))) return rc;
     if ((rc = ensure(ctx, ctx->small, 256))) return rc;
     sc.chunk_masks = (const uint8_t*)ctx->masks.ptr;
     StripeInfo st;
@@ -877,7 +882,7 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
     JEA_HIP(ctx, hipSetDevice(ctx->device));
     EntropyScratch sc;
     int rc;
-    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc))) return rc;
+    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc, true))) return rc;
     if ((rc = ensure(ctx, ctx->out_offsets, sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->out_sizes, sizeof(uint64_t)))) return rc;
     StripeInfo st;

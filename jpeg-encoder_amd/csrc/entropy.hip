@@ -45,7 +45,6 @@ namespace {
 constexpr int kEntThreads = 256;
 constexpr uint32_t kWinWords = 4096;  // 16 KiB LDS window of the packed stream
 constexpr uint32_t kFoldTiles = 4096;  // single images up to this many tiles skip the scan launches
-constexpr uint32_t kLatencyTiles = 32768;  // launches of more tiles than this are bound by throughput
 
 // Exclusive scan of one value per thread over a 256-thread workgroup.
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* lds4, uint32_t& total) {
@@ -812,36 +811,7 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const uint32_t n = (uint32_t)n_images;
     const uint32_t eoi = with_eoi ? 1u : 0u;
 
-    // Many tiles: throughput counts, and the 0xFF tally for all eight alignments costs the bit-length kernel a
-    // little more than a stuffing pass of its own costs (9.8 against 10.1 ms for 1024 frames of 1920x1080 at
-    // quality 90): bit lengths, scans, pack into an unstuffed copy, scans of its 0xFF counts, stuff.
-    if ((uint64_t)n * n_tiles > kLatencyTiles) {
-        if (sc.planar)
-            block_bits_kernel<true, true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                                       sc.slots, d_status, StripeInfo{}, sc.chunk_masks,
-                                                                       sc.mode);
-        else
-            block_bits_kernel<true, false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16,
-                                                                        sc.tile_bits, sc.slots, d_status, StripeInfo{},
-                                                                        sc.chunk_masks, sc.mode);
-        ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
-        scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
-        if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_bits, l1);
-        pack_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
-                                                 sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
-                                                 sc.tile_ff, d_status, StripeInfo{});
-        ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
-        scan_tiles_kernel<<<n, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
-        if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, l2);
-        stuff_kernel<<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
-                                                  sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets, d_sizes,
-                                                  header, (uint32_t)header_len, eoi, d_out, out_capacity, d_status,
-                                                  StripeInfo{});
-        return;
-    }
-
-    // Few tiles: the launches' latencies count.  The bit-length kernel also tallies the 0xFF bytes; one kernel
-    // packs and stuffs.
+    // The bit-length kernel also tallies the 0xFF bytes; one kernel packs and stuffs.
     if (sc.planar)
         tile_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.chunk_masks, sc.mode,
                                                             sc.len16, sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8,

@@ -194,7 +194,8 @@ def test_encode_batch_of_images(ctx, po, jea):
 @pytest.mark.parametrize("n,w,h", [(1, 256, 256), (6, 200, 120), (1, 6000, 4000), (33000, 8, 8)])
 def test_encode_capacity_error_on_every_path(ctx, po, jea, n, w, h):
     """An output buffer a little too small for the last file: capacity error, nothing written past the buffer,
-    and the context keeps working.  One case for each way the coder lays out its launches."""
+    and the context keeps working.  One case for each way the coder lays out its launches (one image summed
+    by its own workgroups, a batch, one image through the scan kernel, more images than a scan pass covers)."""
     quality = 90
     lum, chrom = jea.binding.quant_tables(quality)
     rgb = po.gen_image(w, h, 1 if w * h < 1 << 20 else 0, 5)
@@ -230,8 +231,8 @@ def test_encode_batch_of_noise_at_full_quality(ctx, po, jea):
         assert want[607:-2].count(b"\xff") > 5 or i == 2
 
 
-def test_encode_batch_with_more_tiles_than_the_short_path_takes(ctx, po, jea):
-    """Launches of more than 32768 tiles take the path with a stuffing pass of its own: 33000 pictures of 8x8."""
+def test_encode_batch_of_very_many_small_pictures(ctx, po, jea):
+    """33000 pictures of 8x8 in one call: more images than one pass of the scan over images covers."""
     w = h = 8
     quality, n = 90, 33000
     lum, chrom = jea.binding.quant_tables(quality)
