@@ -657,9 +657,9 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
         // (after one scan over the threads), its alignment, and with that its 0xFF count.
         const uint32_t per_thread = (tile + kEntThreads - 1) / kEntThreads;
         const uint32_t j0 = threadIdx.x * per_thread, j1 = (j0 + per_thread < tile) ? j0 + per_thread : tile;
-        // Up to kRun tiles per thread (any picture up to 1536 tiles, a 4K one has 1286): everything is loaded
+        // Up to kRun tiles per thread (any picture up to 1792 tiles; a 3840x2160 one has 1543): everything is loaded
         // before the scan, all eight counts of each tile, so that no load waits for the scan's result.
-        constexpr uint32_t kRun = 6;
+        constexpr uint32_t kRun = 7;
         const bool short_run = per_thread <= kRun;
         uint32_t run_bits = 0, rb[kRun];
         uint4 rf[kRun];
