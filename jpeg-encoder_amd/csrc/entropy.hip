@@ -415,7 +415,7 @@ __device__ __forceinline__ void or_strings(uint32_t* win, const uint32_t* __rest
 }
 
 template <bool kPlanar>
-__global__ __launch_bounds__(kEntThreads) void tile_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+__global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
                                                                 uint32_t n_tiles,
                                                                 const HuffTables* __restrict__ huff,
                                                                 const uint8_t* __restrict__ chunk_masks,
