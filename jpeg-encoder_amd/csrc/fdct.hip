@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
         for (int c = 0; c < 8; ++c) chunk[c] = lds_coef + j * 128 + ((((uint32_t)c + j) & 7u) << 4);
         // How far do the non-zero coefficients of this wave's 64 blocks reach along the zig-zag?
         // The transform is then run on the smallest triangle u + v <= D that holds them all.
-        bool rest_nonzero;
+        bool rest_nonzero, far_nonzero;   // anything beyond chunk 0 / beyond chunk 1
         if (kPlanar) {
             // The decoder's layout: each thread fetches its block's record and the chunks that exist (the
             // lanes of a wave are consecutive 16-byte elements of a plane) into its LDS slot; chunks
@@ -334,6 +334,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             const uint32_t mask = (rec >> 16) & 0xffu;
             const uint4* plane = reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu + mcu;
             rest_nonzero = (mask >> 1) != 0;
+            far_nonzero = (mask >> 2) != 0;
             uint4 first = make_uint4(rec & 0xffffu, 0, 0, 0);   // DC alone
             if (mask & 1u) first = plane[0];
             *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[0])) = first;
@@ -349,13 +350,15 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
                 *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[1])) = make_uint4(0, 0, 0, 0);
             }
         } else {
-            uint32_t rest = 0;
+            uint32_t rest = 0, far = 0;
 #pragma unroll
             for (int c = 1; c < 8; ++c) {
                 const uint4 c4 = *reinterpret_cast<const uint4*>(chunk[c]);
                 rest |= c4.x | c4.y | c4.z | c4.w;
+                if (c >= 2) far |= c4.x | c4.y | c4.z | c4.w;
             }
             rest_nonzero = rest != 0;
+            far_nonzero = far != 0;
         }
         if (__ballot(rest_nonzero) == 0) {
             // words of the first chunk: zig-zag positions 0-1 | 2-3 | 4-5 | 6-7, which lie on the
@@ -368,12 +371,15 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
                 diag = 0;
                 dc_only = inv_c(0, 0) * (inv_c(0, 0) * ((float)(int)(int16_t)(c0.x & 0xffffu) * qt[0]));
             }
+        } else if (__ballot(far_nonzero) == 0) {
+            diag = 5;   // zig-zag positions 0..15 (chunks 0 and 1) lie on the diagonals u + v <= 5
         }
         switch (diag) {
             case 0: break;
             case 1: idct_rows<1>(chunk, qt, tmp); break;
             case 2: idct_rows<2>(chunk, qt, tmp); break;
             case 3: idct_rows<3>(chunk, qt, tmp); break;
+            case 5: idct_rows<5>(chunk, qt, tmp); break;
             default: idct_rows<7>(chunk, qt, tmp); break;
         }
     }
@@ -391,6 +397,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             case 1: idct_cols<1>(tmp, dst); break;
             case 2: idct_cols<2>(tmp, dst); break;
             case 3: idct_cols<3>(tmp, dst); break;
+            case 5: idct_cols<5>(tmp, dst); break;
             default: idct_cols<7>(tmp, dst); break;
         }
     }
