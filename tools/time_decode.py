@@ -24,5 +24,11 @@ for it in range(3):
     dec = ctx.decode_batch(out, offs, sizes, w, h, lum, chrom)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     print(f"decode {n} x {w}x{h} q{q} mode{mode}: {1e3*(t1-t0):.3f} ms  {n*w*h/(t1-t0)/1e6:.0f} MPix/s  file {sizes[0]} B")
+reps = 200 if n * w * h <= 1 << 24 else 10
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for it in range(reps):
+    dec = ctx.decode_batch(out, offs, sizes, w, h, lum, chrom)
+torch.cuda.synchronize(); t1 = time.perf_counter()
+print(f"{reps} calls back to back: {1e3*(t1-t0)/reps:.3f} ms per call  {reps*n*w*h/(t1-t0)/1e6:.0f} MPix/s")
 want = po.decode(out.cpu().numpy()[offs[0]:offs[0] + sizes[0]].tobytes(), w, h, q)
 print("matches oracle:", np.array_equal(dec.cpu().numpy().reshape(n, h, w, 3)[n - 1], want))
