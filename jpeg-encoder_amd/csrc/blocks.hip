@@ -90,7 +90,7 @@ __global__ void huffman_encode_blocks_kernel(const int16_t* __restrict__ zz, con
                                              const HuffTables* __restrict__ huff, uint16_t* __restrict__ lengths,
                                              uint32_t* __restrict__ bits, int32_t* __restrict__ status) {
     __shared__ HuffLds h;
-    load_huff(h, huff);
+    load_huff<64>(h, huff);   // launched with 64 threads
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

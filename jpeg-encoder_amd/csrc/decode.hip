@@ -230,18 +230,28 @@ __device__ __forceinline__ void stage_group(GroupWords<W, kTail>& gw, const uint
     using G = GroupWords<W, kTail>;
     const int64_t first_word = first_sub * (int64_t)W;
     if (threadIdx.x == 0) gw.w[0] = 0;
-    for (uint32_t i = threadIdx.x; i < G::kWords; i += kThreads) {
-        const int64_t word = first_word + i;
-        const uint64_t byte = (uint64_t)word * 4;
-        uint32_t v = 0;
-        if (word < 0) {
-        } else if (byte + 4 <= ulen) {
-            v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(stream + byte));
-        } else {
-            for (int k = 0; k < 4; ++k)
-                if (byte + k < ulen) v |= (uint32_t)stream[byte + k] << (24 - 8 * k);
+    // four loads under way at a time
+    for (uint32_t i0 = 0; i0 < G::kWords; i0 += 4 * kThreads) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t i = i0 + r * kThreads + threadIdx.x;
+            const int64_t word = first_word + i;
+            const uint64_t byte = (uint64_t)word * 4;
+            v[r] = 0;
+            if (i >= G::kWords || word < 0) {
+            } else if (byte + 4 <= ulen) {
+                v[r] = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(stream + byte));
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    if (byte + k < ulen) v[r] |= (uint32_t)stream[byte + k] << (24 - 8 * k);
+            }
         }
-        gw.w[G::slot(i + 1)] = v;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t i = i0 + r * kThreads + threadIdx.x;
+            if (i < G::kWords) gw.w[G::slot(i + 1)] = v[r];
+        }
     }
 }
 
@@ -270,11 +280,24 @@ struct BitWindow {
     }
 };
 
+// All loads are issued before the first store: written as one loop, every piece waits for the one before it
+// (six round trips to the L2 for the 23 KB).
 __device__ __forceinline__ void load_tables(StepTables& t, const StepTables* __restrict__ g) {
     static_assert(sizeof(StepTables) % 16 == 0, "copied in 16-byte pieces");
+    constexpr uint32_t kPieces = sizeof(StepTables) / 16, kPerThread = (kPieces + kThreads - 1) / kThreads;
     const uint4* src = reinterpret_cast<const uint4*>(g);
     uint4* dst = reinterpret_cast<uint4*>(&t);
-    for (uint32_t i = threadIdx.x; i < sizeof(StepTables) / 16; i += kThreads) dst[i] = src[i];
+    uint4 v[kPerThread];
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; ++r) {
+        const uint32_t i = r * kThreads + threadIdx.x;
+        if (i < kPieces) v[r] = src[i];
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; ++r) {
+        const uint32_t i = r * kThreads + threadIdx.x;
+        if (i < kPieces) dst[i] = v[r];
+    }
 }
 
 constexpr uint32_t kClassBytes = sizeof(StepClass);    // luminance tables first, then chrominance

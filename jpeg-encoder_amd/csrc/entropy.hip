@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
             prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
         }
     }
-    load_huff(h, huff);
+    load_huff<kEntThreads>(h, huff);
     __syncthreads();
     uint32_t bits = 0;
     if (has_block) {
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t
             prev_dc = (b >= 3) ? (int)p[-192] : 0;
         }
     }
-    load_huff(h, huff);
+    load_huff<kEntThreads>(h, huff);
     if (threadIdx.x < 8) count[threadIdx.x] = 0;
     __syncthreads();
 

@@ -15,10 +15,24 @@ struct HuffLds {
     uint32_t ac[2][256];
 };
 
+// kGroup: threads of the workgroup.
+template <uint32_t kGroup>
 __device__ __forceinline__ void load_huff(HuffLds& h, const HuffTables* __restrict__ g) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&h);
-    for (uint32_t i = threadIdx.x; i < sizeof(HuffLds) / 4; i += blockDim.x) dst[i] = src[i];
+    // all loads are issued before the first store (as one loop each piece would wait for the one before it)
+    constexpr uint32_t kWords = sizeof(HuffLds) / 4, kPerThread = (kWords + kGroup - 1) / kGroup;
+    uint32_t v[kPerThread];
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; ++r) {
+        const uint32_t i = r * kGroup + threadIdx.x;
+        if (i < kWords) v[r] = src[i];
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; ++r) {
+        const uint32_t i = r * kGroup + threadIdx.x;
+        if (i < kWords) dst[i] = v[r];
+    }
 }
 
 // The 64 zig-zag coefficients of one block-channel as loaded (8 x 16 bytes).
