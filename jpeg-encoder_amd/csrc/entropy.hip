@@ -6,20 +6,25 @@
 // semantics: a 0x00 after every 0xFF), zero-pads the last byte and appends EOI
 // (encoder.cpp:29-32).  Here the same byte string is produced in parallel:
 //
-//   block_bits_kernel   one thread per block-channel: run-length symbols, Huffman
+//   tile_bits_kernel    one thread per block-channel: run-length symbols, Huffman
 //                       codes and amplitude bits (entropy_encoder.cpp:94-120,
 //                       715-765) assembled MSB first into the block's own slot,
 //                       plus the block's bit length; the DC difference needs only
 //                       the previous MCU's DC of the same channel, read straight
-//                       from the coefficients
-//   scan_tiles_kernel   exclusive scan of the per-tile bit totals of each image
-//   pack_kernel         every tile shifts its blocks' bit strings to their
-//                       scanned bit offsets inside an LDS window and writes the
-//                       bytes it owns of the not-yet-stuffed stream; it also
-//                       counts the 0xFF bytes among them
-//   scan_tiles_kernel   exclusive scan of the per-tile 0xFF counts
-//   stuff_kernel        copies each tile's bytes to their final place,
-//                       inserting 0x00 after 0xFF; writes header and EOI
+//                       from the coefficients.  Then, per tile, the number of 0xFF
+//                       bytes the tile would own for each of the eight bit offsets
+//                       (mod 8) it may end up at
+//   scan_tiles_ff_kernel  batches and pictures of more than 4096 tiles: exclusive scan
+//                       of the per-tile bit totals; each tile's bit base picks its 0xFF
+//                       count, scanned in the same pass (a single smaller picture skips
+//                       this launch: every workgroup of the next kernel sums for itself)
+//   pack_stuff_kernel   every tile shifts its blocks' bit strings to their bit
+//                       offsets inside an LDS window and copies the bytes it owns to
+//                       their final place, inserting 0x00 after 0xFF; header and EOI
+//
+// Stripes of one picture, whose bit offsets come from other contexts between two calls,
+// use block_bits_kernel, scan_tiles_kernel, pack_kernel (into an unstuffed copy,
+// counting its 0xFF bytes), scan_tiles_kernel and stuff_kernel instead.
 //
 // A tile is kTileBlocks = 252 consecutive block-channels (84 MCUs) of one image.
 // Byte ownership: a byte belongs to the tile that holds its first bit, so the
@@ -67,7 +72,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + incl - v;
 }
 
-template <bool kEmit, bool kPlanar>
+template <bool kEmit>
 __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
                                                                  uint32_t n_tiles,
                                                                  const HuffTables* __restrict__ huff,
@@ -89,16 +94,9 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
     if (has_block) {
         // previous DC: same channel, previous MCU; the chain starts at 0 (encoder.cpp:20) or, in a
         // stripe, at the last MCU of the stripe above
-        if (kPlanar) {
-            const uint32_t n_mcu = nbc / 3u, mcu = b / 3u;
-            const uint4* q = reinterpret_cast<const uint4*>(coefs) + ((size_t)img * 24 + ch) * n_mcu + mcu;
-            load_block_planar(blk, q, (size_t)3 * n_mcu, (uint32_t)chunk_masks[(size_t)img * nbc + b]);
-            prev_dc = (b >= 3) ? (int)*reinterpret_cast<const int16_t*>(q - 1) : (int)st.initial_dc[b];
-        } else {
-            const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
-            load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
-            prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
-        }
+        const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
+        load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
+        prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
     }
     load_huff<kEntThreads>(h, huff);
     __syncthreads();
@@ -797,7 +795,7 @@ void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, 
                         ComponentMode mode) {
     const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
-    block_bits_kernel<false, false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
+    block_bits_kernel<false><<<dim3(n_tiles, (unsigned)n_images), kEntThreads, 0, s>>>(
         d_coefs, nbc, n_tiles, d_huff, d_len16, d_tile_bits, nullptr, d_status, StripeInfo{}, nullptr, mode);
 }
 
@@ -861,7 +859,7 @@ void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, cons
                         const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status) {
     const uint32_t nbc = (uint32_t)(mcus * 3);
     const uint32_t n_tiles = tiles_per_image(mcus);
-    block_bits_kernel<true, false><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
+    block_bits_kernel<true><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
                                                                      sc.slots, d_status, st, sc.chunk_masks, sc.mode);
     ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
     scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
