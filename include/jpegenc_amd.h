@@ -98,8 +98,10 @@ int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uin
  * file can be decoded without knowing the quality it was written with:
  *   jea_read_header(file, len, &w, &h, lum, chr);  jea_decode_host(ctx, file, len, w, h, lum, chr, rgb);
  * which equals the reference's decode whenever no table entry exceeded 255 at
- * encode time.  Fails (JEA_ERR_BAD_HEADER) on what jea_check_header rejects and on
- * a table entry of 0.  No counterpart in the reference. */
+ * encode time.  Fails (JEA_ERR_BAD_HEADER) on what jea_check_header rejects, on
+ * a table entry of 0, and on a DHT segment that declares other Huffman tables than
+ * the reference's own (entropy_encoder.cpp:614-694), which are the only ones the
+ * decoder has.  No counterpart in the reference. */
 int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
                     uint16_t chr_q[64]);
 

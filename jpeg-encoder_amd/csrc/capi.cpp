@@ -541,6 +541,12 @@ int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t
         chr_q[kZigzag[k]] = dqt[5 + 65 + k];
         if (dqt[5 + k] == 0 || dqt[5 + 65 + k] == 0) return JEA_ERR_BAD_HEADER;
     }
+    // DHT segment at byte 173 (420 bytes: marker, length, four tables).  The decoder's tables are the ones
+    // the reference writes (entropy_encoder.cpp:614-694); a file that declares others cannot be decoded by
+    // them, and the reference, which skips the segment (encoder.cpp:240), would decode it wrongly.
+    uint8_t own[JEA_HEADER_BYTES];
+    jea_write_header(own, *width, *height, lum_q, chr_q);
+    if (memcmp(own + 173, h_jpeg + 173, 2 + 2 + 4 + 412) != 0) return JEA_ERR_BAD_HEADER;
     return JEA_OK;
 }
 

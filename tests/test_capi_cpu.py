@@ -86,6 +86,12 @@ def test_read_header_returns_the_files_own_tables(jea, po):
     bad = bytearray(jpeg); bad[20 + 4] = 7
     with pytest.raises(jea.JeaError):
         jea.binding.read_header(bytes(bad))
+    # a DHT segment that declares another code (one symbol changed): the strict check of the reference
+    # does not look at it, reading the header for a decode does
+    other = bytearray(jpeg); other[173 + 2 + 2 + 1 + 16 + 3] ^= 1
+    assert jea.binding.check_header(bytes(other))[0]
+    with pytest.raises(jea.JeaError):
+        jea.binding.read_header(bytes(other))
 
 
 def test_missing_library_fails_loudly(jea, monkeypatch, tmp_path):
