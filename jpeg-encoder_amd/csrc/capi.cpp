@@ -961,9 +961,14 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     if ((rc = ensure(ctx, ctx->first_bad, n_images * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ctx_keys, kContextSlots * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->ctx_vals, kContextSlots * sizeof(uint32_t)))) return rc;
-    if (with_headers && (rc = ensure(ctx, ctx->small, hdr_bytes))) return rc;
-    // the pinned block is this context's and the call ends with a wait: the copies may run behind the host
-    JEA_HIP(ctx, hipMemcpyAsync(ctx->seg_offsets.ptr, seg, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the pinned block is this context's and the call ends with a wait: the copy may run behind the host;
+    // a few images' worth goes as kernel arguments instead, which is quicker than the copy engine
+    if (3 * n_images <= kSeedWords) {
+        launch_seed_words(ctx->stream, (uint64_t*)ctx->seg_offsets.ptr, seg, (uint32_t)(3 * n_images));
+        JEA_HIP(ctx, hipGetLastError());
+    } else {
+        JEA_HIP(ctx, hipMemcpyAsync(ctx->seg_offsets.ptr, seg, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     const uint64_t* d_seg = (const uint64_t*)ctx->seg_offsets.ptr;
     auto headers_ok = [&]() -> int {
         for (size_t i = 0; i < n_images; ++i) {
@@ -974,10 +979,10 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
         return JEA_OK;
     };
     if (with_headers) {
-        // one gather and one transfer for the whole batch
-        launch_gather_headers(ctx->stream, d_data, d_seg, n_images, JEA_HEADER_BYTES, (uint8_t*)ctx->small.ptr);
+        // one gather for the whole batch, straight into the pinned block: a copy to the host in this place
+        // would hold up the decoder's kernels behind it for the latency of the copy engine (about 20 us)
+        launch_gather_headers(ctx->stream, d_data, d_seg, n_images, JEA_HEADER_BYTES, hdr);
         JEA_HIP(ctx, hipGetLastError());
-        JEA_HIP(ctx, hipMemcpyAsync(hdr, ctx->small.ptr, hdr_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (too_short) {   // nothing to decode: only the order of the two messages matters
         JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -939,6 +939,21 @@ __global__ void gather_headers_kernel(const uint8_t* __restrict__ data, const ui
 }
 }  // namespace
 
+namespace {
+struct SegmentWords {
+    uint64_t v[kSeedWords];
+};
+__global__ void seed_words_kernel(uint64_t* __restrict__ dst, SegmentWords words, uint32_t count) {
+    if (threadIdx.x < count) dst[threadIdx.x] = words.v[threadIdx.x];
+}
+}  // namespace
+
+void launch_seed_words(hipStream_t s, uint64_t* d_dst, const uint64_t* h_words, uint32_t count) {
+    SegmentWords w{};
+    for (uint32_t i = 0; i < count && i < kSeedWords; ++i) w.v[i] = h_words[i];
+    seed_words_kernel<<<1, kSeedWords, 0, s>>>(d_dst, w, count);
+}
+
 void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
                            uint32_t header_bytes, uint8_t* d_out) {
     gather_headers_kernel<<<(unsigned)n_images, 256, 0, s>>>(d_data, d_scan_offsets, header_bytes, d_out);

@@ -230,8 +230,15 @@ hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const D
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const std::function<void()>& follow_up, DecodeReport* report);
 
+// A few 64-bit words from the host to device memory as kernel arguments: a launch instead of a copy, which
+// on a stream costs the latency of the copy engine (count <= kSeedWords).
+constexpr uint32_t kSeedWords = 48;
+void launch_seed_words(hipStream_t s, uint64_t* d_dst, const uint64_t* h_words, uint32_t count);
+
 // Copies the header_bytes bytes in front of each scan (d_scan_offsets[i] is the scan's offset in
-// d_data) to d_out back to back, so that the host can validate all headers with one transfer.
+// d_data) to d_out back to back, so that the host can validate all headers in one go.  d_out may be
+// pinned host memory: the kernel then delivers the headers itself, and no copy sits in the stream
+// between the decoder's kernels.
 void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
                            uint32_t header_bytes, uint8_t* d_out);
 
