@@ -857,12 +857,14 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     const uint64_t first_bit = ((uint64_t)group * kOwned + tid) * kSubBits;
     const bool active = tid < kOwned && first_bit < total_bits;
 
+    // asked for first, so that they are under way while tables and stream are staged
+    const int4 si = tid < kOwned ? sub_info[sub_index] : make_int4(0, 0, 0, 0);
+    const uint32_t start_state = tid < kOwned ? sub_used[sub_index] : 0u;
     load_tables(t, tables);
     const uint8_t* stream = ustream + ubase[img];
     stage_group(gw, stream, ulen, (int64_t)group * kOwned);
     for (uint32_t i = 0; i < kAccWords; ++i) acc[tid * kAccWords + i] = 0;
 
-    const int4 si = tid < kOwned ? sub_info[sub_index] : make_int4(0, 0, 0, 0);
     Sums total;
     const Sums before = block_exclusive_scan(Sums{si.x, si.y, si.z, si.w}, lds4, total);   // also orders the staging
     WriteTarget wt;
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     wt.final_bit = 0;
     if (!active || wt.block >= total_blocks) return;
 
-    write_blocks<W, kPlanar>(gw, t, acc + tid * kAccWords, lum_mask, tid, sub_used[sub_index], wt);
+    write_blocks<W, kPlanar>(gw, t, acc + tid * kAccWords, lum_mask, tid, start_state, wt);
     if (wt.error) {
         // a malformed symbol outranks a missing end marker, as in the serial order of checks
         const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
