@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
                                                                    uint64_t* __restrict__ img_drops,
                                                                    const uint64_t* __restrict__ ubase,
                                                                    uint8_t* __restrict__ ustream) {
-    __shared__ uint8_t kept[kChunkBytes];
+    __shared__ __align__(16) uint8_t kept[kChunkBytes + 4];
     __shared__ uint32_t wsum[4];
     __shared__ uint64_t fold4[4];
     const uint32_t chunk = blockIdx.x, img = blockIdx.y;
@@ -204,7 +204,20 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
     const uint32_t in_chunk = (uint32_t)((len - c0 < kChunkBytes) ? len - c0 : kChunkBytes);
     const uint32_t n_kept = in_chunk - total_drops;
     uint8_t* dst = ustream + ubase[img] + c0 - drops_before;
-    for (uint32_t i = threadIdx.x; i < n_kept; i += kThreads) dst[i] = kept[i];
+    // bytes up to the first 4-byte boundary of the destination, then whole words put together from two
+    // aligned LDS words each, then the last bytes
+    uint32_t head = (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
+    head = head < n_kept ? head : n_kept;
+    if (threadIdx.x < head) dst[threadIdx.x] = kept[threadIdx.x];
+    const uint32_t n_words = (n_kept - head) >> 2;
+    const uint32_t* k32 = reinterpret_cast<const uint32_t*>(kept);
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+    for (uint32_t q = threadIdx.x; q < n_words; q += kThreads) {
+        const uint32_t from = head + 4u * q;
+        d32[q] = __builtin_amdgcn_alignbyte(k32[(from >> 2) + 1], k32[from >> 2], from & 3u);
+    }
+    const uint32_t rest = head + 4u * n_words + threadIdx.x;
+    if (rest < n_kept) dst[rest] = kept[rest];
 }
 
 // ---------------------------------------------------------------------------
