@@ -363,19 +363,21 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
     }
 
     uint64_t carry = 0;  // 0xFF bytes of this tile before the current chunk
-    for (uint64_t c0 = b0; c0 < b1; c0 += (uint64_t)kEntThreads * 16) {
-        const uint64_t i0 = c0 + (uint64_t)threadIdx.x * 16;
-        uint8_t v[16];
+    // four bytes per thread and step: the bytes one store instruction of a wave writes lie close together
+    constexpr int kBytes = 4;
+    for (uint64_t c0 = b0; c0 < b1; c0 += (uint64_t)kEntThreads * kBytes) {
+        const uint64_t i0 = c0 + (uint64_t)threadIdx.x * kBytes;
+        uint8_t v[kBytes];
         uint32_t cnt = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < kBytes; ++k) {
             v[k] = (i0 + k < b1) ? src[i0 + k] : 0;
             cnt += (v[k] == 0xFF);
         }
         uint32_t total;
         uint64_t pos = carry + block_exclusive_scan_256(cnt, wsum, total);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < kBytes; ++k) {
             if (i0 + k < b1) {
                 dst[i0 + k + pos] = v[k];
                 if (v[k] == 0xFF) {
