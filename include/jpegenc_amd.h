@@ -125,6 +125,28 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
                            const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out,
                            size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
 
+/* jea_encode_batch_async for callers that cannot allocate device memory while they
+ * call: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  It has no counterpart in the reference.  Same arguments, same
+ * kernels, same output, but the scratch (coefficients, bit strings, per-tile
+ * sums) lives in a buffer of JEA_STATIC_SCRATCH_BYTES that is part of the loaded
+ * library -- one copy per GPU, held until the process ends -- so the call makes no
+ * hipMalloc / hipFree and never synchronises.  Limits:
+ *   - jea_static_scratch_needed(n_images, width, height) must not exceed
+ *     JEA_STATIC_SCRATCH_BYTES (one 1920x1080 image needs 33.5 MB; the need grows
+ *     with n_images * MCUs); larger jobs get JEA_ERR_CAPACITY and a message that
+ *     states both numbers, and nothing is enqueued;
+ *   - all contexts of a GPU share that GPU's buffer: calls whose GPU work overlaps
+ *     on one GPU (two contexts, or two streams) race.  Calls on one stream, one
+ *     after the other, are fine: nothing in the buffer has to survive or to be
+ *     cleared between calls. */
+#define JEA_STATIC_SCRATCH_BYTES (48u << 20)
+size_t jea_static_scratch_needed(size_t n_images, uint16_t width, uint16_t height);
+int jea_encode_batch_static_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width,
+                                  uint16_t height, const uint16_t lum_q[64], const uint16_t chr_q[64],
+                                  uint8_t* d_out, size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes,
+                                  int32_t* d_status);
+
 /* One image held in host memory: copies it to the GPU, encodes, copies the file
  * back.  This is what BaselineEncoder::encode(BitmapImageRGB const&, JPEGImage&)
  * calls.  h_out must hold out_capacity bytes; *out_len receives the file size. */

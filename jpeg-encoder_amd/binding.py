@@ -15,6 +15,7 @@ EXPORTS = [
     "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_set_colour_mapper", "jea_get_stream", "jea_synchronize",
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
+    "jea_encode_batch_static_async", "jea_static_scratch_needed",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
     "jea_decode_batch", "jea_decode_host",
     "jea_fdct_quant", "jea_fdct_quant_async", "jea_fdct_quant_planar_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
@@ -67,6 +68,9 @@ def load_library():
     lib.jea_encode_batch.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp]
     lib.jea_encode_batch_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
     lib.jea_encode_host.argtypes = [vp, vp, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
+    lib.jea_encode_batch_static_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
+    lib.jea_static_scratch_needed.argtypes = [sz, u16, u16]
+    lib.jea_static_scratch_needed.restype = sz
     lib.jea_stripe_transform.argtypes = [vp, vp, u16, u16, vp, vp, vp]
     lib.jea_stripe_bits.argtypes = [vp, vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint32)]
     lib.jea_stripe_finish.argtypes = [vp, c.c_uint64, i32, i32, c.c_uint32, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
@@ -137,6 +141,13 @@ def read_header(jpeg):
     if rc:
         raise JeaError(rc, "jea_read_header: not a file of this format")
     return w.value, h.value, lum, chrom
+
+
+STATIC_SCRATCH_BYTES = 48 << 20
+
+
+def static_scratch_needed(n_images, w, h):
+    return load_library().jea_static_scratch_needed(n_images, w, h)
 
 
 def n_mcu(w, h):
@@ -340,6 +351,13 @@ class Context:
         self._check(self.lib.jea_encode_batch_async(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
                                                     chrom.ctypes.data, d_out.data_ptr(), d_out.numel(),
                                                     d_offsets.data_ptr(), d_sizes.data_ptr(), d_status.data_ptr()))
+
+    def encode_batch_static_async(self, d_rgb, n_images, w, h, lum, chrom, d_out, d_offsets, d_sizes, d_status):
+        """jea_encode_batch_async on the library's built-in scratch: no allocation inside the call."""
+        self._check(self.lib.jea_encode_batch_static_async(self.handle, d_rgb.data_ptr(), n_images, w, h,
+                                                           lum.ctypes.data, chrom.ctypes.data, d_out.data_ptr(),
+                                                           d_out.numel(), d_offsets.data_ptr(), d_sizes.data_ptr(),
+                                                           d_status.data_ptr()))
 
     def encode_host(self, rgb, lum, chrom, capacity=None):
         h, w = rgb.shape[:2]

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,9 +24,35 @@
 
 using namespace jea;
 
+// Scratch of jea_encode_batch_static_async: device memory that exists from the moment the library is loaded,
+// one copy per GPU, so that the call itself allocates nothing.  In host code this name is only a handle for
+// hipGetSymbolAddress; the address of a GPU's copy is looked up once per device (static_scratch_of) and
+// only that address is ever handed to kernels.
+constexpr size_t kStaticScratchBytes = (size_t)JEA_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on the current device (which must be `device`); asked for once per device.
+hipError_t static_scratch_of(int device, unsigned char** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 struct DeviceBuffer {
     void* ptr = nullptr;
@@ -44,6 +71,7 @@ struct jea_ctx {
     StepTables* d_steps = nullptr;
     int32_t* d_status = nullptr;
     ComponentMode mode;   // jea_set_colour_mapper
+    unsigned char* static_scratch = nullptr;   // this GPU's copy of `scratch`
     // scratch, grown on demand and kept
     DeviceBuffer coefs, masks, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
     DeviceBuffer stage_in, stage_out, seg_offsets, out_offsets, out_sizes;
@@ -400,6 +428,7 @@ int jea_create(int device_id, jea_ctx** out_ctx) {
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     ctx->stream = ctx->own_stream;
+    if ((e = static_scratch_of(device_id, &ctx->static_scratch)) != hipSuccess) return bail("hipGetSymbolAddress", e);
 
     HuffTables ht;
     build_codes(kDcLumBits, kDcVals, ht.dc[0], 12);
@@ -752,31 +781,116 @@ int jea_entropy_encode(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, si
 
 // ---- whole encode -------------------------------------------------------------
 
+// The launches of a whole encode, given scratch that is large enough: forward kernel into chunk-planar
+// coefficients (all-zero chunks not even written), then the entropy kernels.
+static int enqueue_encode(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                          const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs, uint8_t* d_masks,
+                          EntropyScratch sc, uint8_t* d_out, size_t out_capacity, uint64_t* d_offsets,
+                          uint64_t* d_sizes, int32_t* d_status) {
+    const size_t mcus = mcus_of(width, height);
+    HeaderBytes hb{};
+    jea_write_header(hb.b, width, height, lum_q, chr_q);
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status,
+                      d_masks, true, ctx->mode);
+    JEA_HIP(ctx, hipGetLastError());
+    sc.chunk_masks = d_masks;
+    sc.planar = true;
+    launch_entropy_encode(ctx->stream, d_coefs, n_images, mcus, ctx->d_huff, sc, hb, JEA_HEADER_BYTES, true, d_out,
+                          out_capacity, d_offsets, d_sizes, d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    return JEA_OK;
+}
+
+static bool encode_args_ok(const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                           const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
+                           uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
+    return d_rgb && d_out && d_offsets && d_sizes && d_status && n_images != 0 && n_images <= 65535 &&
+           valid_dims(width, height) && tables_ok(lum_q, chr_q) && out_capacity >= JEA_HEADER_BYTES + 3;
+}
+
 int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
                            const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
                            uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
     if (!ctx) return JEA_ERR_INVALID_ARG;
-    if (!d_rgb || !d_out || !d_offsets || !d_sizes || !d_status || n_images == 0 || n_images > 65535 ||
-        !valid_dims(width, height) || !tables_ok(lum_q, chr_q) || out_capacity < JEA_HEADER_BYTES + 3)
+    if (!encode_args_ok(d_rgb, n_images, width, height, lum_q, chr_q, d_out, out_capacity, d_offsets, d_sizes, d_status))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
     const size_t mcus = mcus_of(width, height);
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
     if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3))) return rc;
-    int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
-    uint8_t* d_masks = (uint8_t*)ctx->masks.ptr;
     // scratch first: growing a buffer synchronises the stream, which must not happen between the launches
     EntropyScratch sc;
     if ((rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc))) return rc;
-    HeaderBytes hb{};
-    jea_write_header(hb.b, width, height, lum_q, chr_q);
-    // the coefficients stay inside the library: chunk-planar layout, all-zero chunks not even written
-    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status,
-                      d_masks, true, ctx->mode);
-    JEA_HIP(ctx, hipGetLastError());
-    return entropy_encode_common(ctx, d_coefs, n_images, mcus, hb, JEA_HEADER_BYTES, true, d_out, out_capacity,
-                                 d_offsets, d_sizes, d_status, true, d_masks, true);
+    return enqueue_encode(ctx, d_rgb, n_images, width, height, lum_q, chr_q, (int16_t*)ctx->coefs.ptr,
+                          (uint8_t*)ctx->masks.ptr, sc, d_out, out_capacity, d_offsets, d_sizes, d_status);
+}
+
+// Bytes of `scratch` an encode of n_images pictures of `mcus` MCUs each takes: the same buffers that
+// jea_encode_batch_async keeps per context, each starting at a multiple of 256 bytes.
+namespace {
+struct StaticLayout {
+    size_t coefs, masks, len16, slots, tile_bits, tile_base, tile_ffbase, img_words, tile_ff8, total;
+};
+StaticLayout static_layout(size_t n_images, size_t mcus) {
+    const size_t nbc = mcus * 3, n_tiles = tiles_per_image(mcus);
+    StaticLayout l{};
+    size_t at = 0;
+    auto take = [&at](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) & ~(size_t)255;
+        return here;
+    };
+    l.coefs = take(n_images * nbc * 64 * sizeof(int16_t));
+    l.masks = take(n_images * nbc);
+    l.len16 = take(n_images * nbc * sizeof(uint16_t));
+    l.slots = take(n_images * n_tiles * (size_t)kSlotWords * kSlotStride * sizeof(uint32_t));
+    l.tile_bits = take(n_images * n_tiles * sizeof(uint32_t));
+    l.tile_base = take(n_images * n_tiles * sizeof(uint64_t));
+    l.tile_ffbase = take(n_images * n_tiles * sizeof(uint64_t));
+    l.img_words = take(3 * n_images * sizeof(uint64_t));
+    l.tile_ff8 = take(n_images * n_tiles * 4 * sizeof(uint32_t));
+    l.total = at;
+    return l;
+}
+}  // namespace
+
+size_t jea_static_scratch_needed(size_t n_images, uint16_t width, uint16_t height) {
+    if (n_images == 0 || !valid_dims(width, height)) return 0;
+    return static_layout(n_images, mcus_of(width, height)).total;
+}
+
+int jea_encode_batch_static_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width,
+                                  uint16_t height, const uint16_t lum_q[64], const uint16_t chr_q[64],
+                                  uint8_t* d_out, size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes,
+                                  int32_t* d_status) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!encode_args_ok(d_rgb, n_images, width, height, lum_q, chr_q, d_out, out_capacity, d_offsets, d_sizes, d_status))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch_static_async: invalid argument");
+    const size_t mcus = mcus_of(width, height);
+    const StaticLayout l = static_layout(n_images, mcus);
+    if (l.total > kStaticScratchBytes)
+        return fail(ctx, JEA_ERR_CAPACITY,
+                    "jea_encode_batch_static_async: " + std::to_string(n_images) + " image(s) of " +
+                        std::to_string(width) + "x" + std::to_string(height) + " need " + std::to_string(l.total) +
+                        " bytes of scratch, the built-in buffer has " + std::to_string(kStaticScratchBytes) +
+                        "; use jea_encode_batch_async");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned char* const base = ctx->static_scratch;   // this GPU's copy, found in jea_create
+    EntropyScratch sc{};
+    sc.len16 = (uint16_t*)(base + l.len16);
+    sc.mode = ctx->mode;
+    sc.slots = (uint32_t*)(base + l.slots);
+    sc.tile_bits = (uint32_t*)(base + l.tile_bits);
+    sc.tile_base = (uint64_t*)(base + l.tile_base);
+    sc.tile_ffbase = (uint64_t*)(base + l.tile_ffbase);
+    sc.img_bits = (uint64_t*)(base + l.img_words);
+    sc.img_ubase = sc.img_bits + n_images;
+    sc.img_ff = sc.img_ubase + n_images;
+    sc.tile_ff8 = (uint32_t*)(base + l.tile_ff8);
+    // tile_ff and unstuffed stay null: only the stripe kernels use them
+    return enqueue_encode(ctx, d_rgb, n_images, width, height, lum_q, chr_q, (int16_t*)(base + l.coefs),
+                          base + l.masks, sc, d_out, out_capacity, d_offsets, d_sizes, d_status);
 }
 
 int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
