@@ -53,8 +53,8 @@ __global__ void dct_inverse_blocks_kernel(const float* __restrict__ in, size_t n
     for (int k = 0; k < 64; ++k) out[i * 64 + k] = px[k];
 }
 
-// Quantiser::quantise (quantiser.cpp:57-70), natural order in and out; same
-// reciprocal fast path + exact fallback as the fused kernel.
+// Quantiser::quantise (quantiser.cpp:57-70), natural order in and out; the same
+// division-free quotient as the fused kernel.
 __global__ void quantise_blocks_kernel(const float* __restrict__ in, size_t n, QuantTables q, int use_lum,
                                        int16_t* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,7 +67,10 @@ __global__ void quantise_blocks_kernel(const float* __restrict__ in, size_t n, Q
         float o[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) o[v] = in[i * 64 + 8 * v + u];
-        quantise_col(o, qt, rqt, u, qv);
+        float2 c[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) c[v] = make_float2(rqt[8 * u + v], qt[8 * u + v]);   // tables are stored [u][v]
+        quantise_col(o, c, u, qv);
     }
 #pragma unroll
     for (int k = 0; k < 64; ++k) out[i * 64 + k] = (int16_t)qv[k];

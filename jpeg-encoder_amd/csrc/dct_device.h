@@ -118,35 +118,31 @@ __device__ __forceinline__ int quantise_exact(float o, float q) {
     return (int)floor(0.5 + (double)quot);
 }
 
-// The same value from a reciprocal multiply.  t = o * rq differs from the
-// correctly rounded quotient by less than |t| * 2^-22 (rq = RN(1/q) and the
-// product each contribute at most 2^-24 relative, the reference's own division
-// another 2^-24), so floor(t + 0.5) is the reference's result unless t lies
-// within that distance of a half-integer; such lanes are flagged and redone
-// with quantise_exact.  v_cvt_rpi_i32_f32 is floor(x + 0.5) as an integer; its
-// own rounding of x + 0.5 is covered by the same margin.  The test runs once per column of eight.
-// Returns the rounded value; `margin` receives (distance of t to the nearest half-integer) minus
-// |t| * 2^-20: the value is settled when margin >= 2^-22.
-__device__ __forceinline__ int quantise_fast(float o, float rq, float& margin) {
-    const float t = o * rq;
+// The same value without a division.  With rq = RN(1/q):
+//   q0 = RN(o * rq)            within an ulp of o / q
+//   r  = RN(o - q0 * q)        one FMA; exact, because q0 is that close
+//   q1 = RN(q0 + r * rq)       one FMA; the correctly rounded quotient RN(o / q)
+// (Markstein's correction step; it needs rq to be the correctly rounded reciprocal, which it is for
+// every integer q = 1..65535.  Checked against the division on the host over all those q with
+// millions of dividends including the neighbours of every q * (n + 1/2); the two differ only where the
+// quotient is subnormal, and those round to 0 either way.)  Then floor(0.5 + double(q1)): the double
+// sum is exact, and v_cvt_rpi_i32_f32 returns floor(x + 0.5) of the exact sum for every float x
+// (compared with the double formula over all 2^32 bit patterns, tools/probe_insts.hip).
+// Every operand is a vector register: on gfx950 an f32 multiply or FMA with a scalar-register
+// operand issues at half the rate, so the callers bring rq and q in through LDS or registers.
+__device__ __forceinline__ int quantise_rn(float o, float rq, float q) {
+    const float q0 = o * rq;
+    const float r = __builtin_fmaf(-q0, q, o);
+    const float q1 = __builtin_fmaf(r, rq, q0);
     int n;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(n) : "v"(t));
-    const float s = __builtin_amdgcn_fractf(t) - 0.5f;
-    margin = __builtin_fmaf(-__builtin_fabsf(t), 0x1p-20f, __builtin_fabsf(s));
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(n) : "v"(q1));
     return n;
 }
 
-// Quantises the eight coefficients out[8v+u], v = 0..7, of one column u.
-__device__ __forceinline__ void quantise_col(const float (&o)[8], const float* __restrict__ qt,
-                                             const float* __restrict__ rqt, int u, int* __restrict__ qv) {
-    float m[8];
+// Quantises the eight coefficients out[8v+u], v = 0..7, of one column u; c[v] = {RN(1/Q), Q} of entry 8v+u.
+__device__ __forceinline__ void quantise_col(const float (&o)[8], const float2 (&c)[8], int u, int* __restrict__ qv) {
 #pragma unroll
-    for (int v = 0; v < 8; ++v) qv[8 * v + u] = quantise_fast(o[v], rqt[8 * u + v], m[v]);  // tables are stored [u][v]
-    const float worst = min3(min3(m[0], m[1], m[2]), min3(m[3], m[4], m[5]), min3(m[6], m[7], m[7]));
-    if (__builtin_expect(worst < 0x1p-22f, 0)) {
-#pragma unroll
-        for (int v = 0; v < 8; ++v) qv[8 * v + u] = quantise_exact(o[v], qt[8 * u + v]);
-    }
+    for (int v = 0; v < 8; ++v) qv[8 * v + u] = quantise_rn(o[v], c[v].x, c[v].y);
 }
 
 // colour_mapping.cpp:77-85; (C - 128) is formed in integer arithmetic first.

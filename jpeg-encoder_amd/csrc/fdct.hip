@@ -35,8 +35,11 @@ namespace {
 constexpr int kMcusPerGroup = 64;
 constexpr int kFdctThreads = 192;
 
+#ifndef JEA_K1_MIN_WAVES
+#define JEA_K1_MIN_WAVES 5
+#endif
 template <bool kFast, bool kPlanar>
-__global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t* __restrict__ rgb, int width,
+__global__ __launch_bounds__(kFdctThreads, JEA_K1_MIN_WAVES) void fdct_quant_kernel(const uint8_t* __restrict__ rgb, int width,
                                                                   int height, int blocks_w, uint32_t n_mcu,
                                                                   size_t image_bytes, QuantTables q,
                                                                   int16_t* __restrict__ coefs,
@@ -55,8 +58,16 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
     __shared__ __align__(16) uint8_t lds[kPlanar ? 8 * kMcusPerGroup * 24 : kFdctThreads * 128];
     uint8_t* const lds_in = lds;
     uint8_t* const lds_out = lds;
+    // {RN(1/Q), Q} of both quantisation tables in the order the column pass walks them ([u][v]): read from
+    // here they reach the quantiser in vector registers (a scalar-register operand would halve its issue rate)
+    __shared__ float2 lds_qt[128];
 
     const int tid = threadIdx.x;
+    if (tid < 128) {
+        // lum_t | chr_t and rlum_t | rchr_t lie side by side in QuantTables
+        const float* qb = reinterpret_cast<const float*>(&q);
+        lds_qt[tid] = make_float2(qb[256 + tid], qb[128 + tid]);
+    }
     const uint32_t g0 = blockIdx.x * kMcusPerGroup;
     const uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
     const uint32_t mcus_here = (n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup;
@@ -120,9 +131,12 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
         double ck, ca, cb, cc;
         colour_constants(channel, ck, ca, cb, cc);
         ColourInt ci = colour_int_constants(channel);
-        // the constant term lives in a vector register: as a scalar it would be copied there again for
-        // every pixel (an fma takes one scalar operand, and the coefficient is the other)
+        // all four constants live in vector registers: an FMA with a scalar-register operand issues at half
+        // the rate of one whose operands are all vector registers
         asm volatile("v_mov_b32 %0, %1" : "=v"(ci.k) : "s"(ci.k));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci.a) : "s"(ci.a));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci.b) : "s"(ci.b));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci.c) : "s"(ci.c));
         if (mode.passthrough) {
             // RGBToRGBMapper (colour_mapping.cpp:16-26): the component as it is.  A loop of its own,
             // so that the usual path carries no test per pixel.
@@ -172,14 +186,16 @@ __global__ __launch_bounds__(kFdctThreads) void fdct_quant_kernel(const uint8_t*
     __syncthreads();  // every wave is done with lds_in: the buffer becomes lds_out
 
     if (active) {
-        const float* qt = mode.is_lum(channel) ? q.lum_t : q.chr_t;
-        const float* rqt = mode.is_lum(channel) ? q.rlum_t : q.rchr_t;
+        const float2* qtab = lds_qt + (mode.is_lum(channel) ? 0 : 64);
         int qv[64];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float o[8];
             fdct_col(row, u, o);
-            quantise_col(o, qt, rqt, u, qv);
+            float2 c[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) c[v] = qtab[8 * u + v];
+            quantise_col(o, c, u, qv);
         }
         // zig-zag (entropy_encoder.cpp:15-77); hand-over through LDS, or, chunk-planar, straight to
         // memory: the lanes of a wave are consecutive MCUs of one channel, i.e. consecutive 16-byte

@@ -52,8 +52,9 @@ def test_quantise_blocks_adversarial(ctx, po):
         n = rng.randint(-1100 // max(1, table_val) - 2, 1100 // max(1, table_val) + 3, 64 * 6)
         half = (n.astype(np.float64) + 0.5) * table_val
         x = half.astype(np.float32)
-        ulps = rng.randint(-3, 4, x.shape)
+        ulps = rng.randint(-3, 4, x.shape).astype(np.int32)   # int32: the sum must stay 32 bits wide for the view
         x = (x.view(np.int32) + ulps).view(np.float32).reshape(-1, 64)
+        assert x.shape == (6, 64) and np.isfinite(x).all()
         assert np.array_equal(ctx.quantise_blocks(x, table), po.quantise_blocks(x, table)), table_val
     # exact integers and exact halves
     table = np.arange(1, 65, dtype=np.uint16)

@@ -1,35 +1,66 @@
-"""A/B of fused-forward-kernel builds in one process: average launch time over interleaved rounds."""
-import ctypes, importlib, os, sys, glob
+"""A/B of fused-forward-kernel builds in one process: launch time of the chunk-planar variant (the one
+the fused encode runs) for one 4K image and the marginal time per image in an eight-image launch,
+interleaved over rounds so that clock drift hits every build alike.
+
+usage: ab_k1.py [mode]     builds = jpeg-encoder_amd/libjpegenc_amd_*.so (made by tools/build_variant.sh)
+"""
+import glob
+import importlib
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
-import numpy as np, torch
+import numpy as np
+import torch
 import pyoracle as po
+
 pkg = importlib.import_module("jpeg-encoder_amd")
 b = pkg.binding
 libs = sorted(glob.glob(os.path.join(ROOT, "jpeg-encoder_amd", "libjpegenc_amd_*.so")))
+libs.insert(0, os.path.join(ROOT, "jpeg-encoder_amd", "libjpegenc_amd.so"))
 W, H = 3840, 2160
+NB = 8
 lum, chrom = b.quant_tables(75)
-batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-imgs = np.stack([po.gen_image(W, H, 0, 1234 + i) for i in range(batch)])
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+imgs = np.stack([po.gen_image(W, H, mode, 1234 + i) for i in range(NB)])
 ctxs = {}
 for path in libs:
-    b._lib = None; b.LIB_PATH = path
+    b._lib = None
+    b.LIB_PATH = path
     ctxs[os.path.basename(path)] = pkg.Context(0)
-res = {k: [] for k in ctxs}
-for k, ctx in ctxs.items():
-    ctx.d_rgb = ctx.to_device(imgs.reshape(-1))
-    ctx.d_coefs = torch.empty(batch * b.n_mcu(W, H) * 192, dtype=torch.int16, device=ctx.tdev)
-    ctx.ext = torch.cuda.ExternalStream(ctx.stream_handle, device=ctx.tdev)
-for rnd in range(6):
-    for k, ctx in ctxs.items():
-        with torch.cuda.stream(ctx.ext):
-            for _ in range(3): ctx.fdct_quant_async(ctx.d_rgb, batch, W, H, lum, chrom, ctx.d_coefs)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(30): ctx.fdct_quant_async(ctx.d_rgb, batch, W, H, lum, chrom, ctx.d_coefs)
-            e1.record()
-        ctx.synchronize()
-        res[k].append(e0.elapsed_time(e1) / 30 * 1e3 / batch)
+d_rgb = None
 ref = None
+for k, ctx in ctxs.items():
+    if d_rgb is None:
+        d_rgb = ctx.to_device(imgs.reshape(-1))
+    ctx.d_coefs = torch.zeros(NB * b.n_mcu(W, H) * 192, dtype=torch.int16, device=ctx.tdev)
+    ctx.d_masks = torch.zeros(NB * b.n_mcu(W, H) * 3, dtype=torch.uint8, device=ctx.tdev)
+    ctx.ext = torch.cuda.ExternalStream(ctx.stream_handle, device=ctx.tdev)
+    ctx.fdct_quant_planar_async(d_rgb, NB, W, H, lum, chrom, ctx.d_coefs, ctx.d_masks)
+    ctx.synchronize()
+    # unwritten chunks keep the zeros the buffers started with, so equal outputs mean equal coefficients
+    got = (ctx.d_coefs.clone(), ctx.d_masks.clone())
+    if ref is None:
+        ref = got
+    else:
+        same = torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+        print("%-40s output %s the first build's" % (k, "EQUALS" if same else "DIFFERS FROM"))
+res = {k: {1: [], NB: []} for k in ctxs}
+for rnd in range(7):
+    for k, ctx in ctxs.items():
+        for n, reps in ((1, 40), (NB, 10)):
+            with torch.cuda.stream(ctx.ext):
+                for _ in range(3):
+                    ctx.fdct_quant_planar_async(d_rgb, n, W, H, lum, chrom, ctx.d_coefs, ctx.d_masks)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    ctx.fdct_quant_planar_async(d_rgb, n, W, H, lum, chrom, ctx.d_coefs, ctx.d_masks)
+                e1.record()
+            ctx.synchronize()
+            res[k][n].append(e0.elapsed_time(e1) / reps * 1e3)
+med = lambda v: sorted(v)[len(v) // 2]
 for k, v in res.items():
-    print("%-36s median %.2f us/image  min %.2f" % (k, sorted(v)[len(v) // 2], min(v)))
+    one, many = med(v[1]), med(v[NB])
+    print("%-40s 1 image %.2f us   %d images %.2f us   marginal %.2f us/image" % (k, one, NB, many, (many - one) / (NB - 1)))
