@@ -64,6 +64,27 @@ void* jea_get_stream(jea_ctx* ctx);
 /* Blocks until all work enqueued on the context's stream has finished. */
 int jea_synchronize(jea_ctx* ctx);
 
+/* Upper bound (bytes, default 32 GiB) of the scratch one whole-encode call may keep per context: the
+ * coefficients and worst-case bit strings of an image take 15.9 bytes per pixel, so a batch of 1024
+ * 1920x1080 frames would take 34 GB.  A batch that needs more than the budget is encoded in passes of as
+ * many images as fit, on the same stream; files, offsets and sizes are the same as from one pass.  When
+ * even a buffer within the budget does not fit the GPU's free memory the call returns JEA_ERR_CAPACITY.
+ * No counterpart in the reference (which holds one block at a time). */
+int jea_set_scratch_budget(jea_ctx* ctx, size_t bytes);
+
+/* Timing of the library's own kernels, for benchmarks (no counterpart in the reference, whose demo
+ * times whole calls with std::chrono, examples/encode-decode.cpp:103-121).  While profiling is on, the
+ * whole-encode and whole-decode entry points record HIP events on the context's stream at their phase
+ * boundaries; jea_last_phase_ms waits for the last of them and returns the phases' durations in
+ * milliseconds:
+ *   encode (jea_encode_batch[_async], jea_encode_batch_static_async, jea_encode_host): 3 phases --
+ *     forward transform kernel | bit-string kernel | scans + pack-and-stuff kernel;
+ *   decode (jea_decode_batch, jea_decode_host, jea_entropy_decode): 4 phases --
+ *     unstuffing | the two synchronisation rounds | scan + write pass | inverse transform kernel.
+ * Events between kernels cost a little; leave profiling off when measuring throughput. */
+int jea_set_profiling(jea_ctx* ctx, int on);
+int jea_last_phase_ms(jea_ctx* ctx, float* ms, size_t capacity, size_t* n_phases);
+
 /* ---- tables (host-side helpers, no GPU work) -------------------------- */
 
 /* Colour mapper of everything the context does from now on (default JEA_MAPPER_YCBCR):

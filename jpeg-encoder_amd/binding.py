@@ -13,6 +13,7 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "HIP", 3: "CAPACITY", 4: "RANGE", 5: "BAD_HEAD
 
 EXPORTS = [
     "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_set_colour_mapper", "jea_get_stream", "jea_synchronize",
+    "jea_set_profiling", "jea_last_phase_ms", "jea_set_scratch_budget",
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_encode_batch_static_async", "jea_static_scratch_needed",
@@ -57,6 +58,9 @@ def load_library():
     lib.jea_get_stream.argtypes = [vp]
     lib.jea_get_stream.restype = vp
     lib.jea_synchronize.argtypes = [vp]
+    lib.jea_set_scratch_budget.argtypes = [vp, sz]
+    lib.jea_set_profiling.argtypes = [vp, i32]
+    lib.jea_last_phase_ms.argtypes = [vp, vp, sz, c.POINTER(sz)]
     lib.jea_quant_tables.argtypes = [i32, vp, vp]
     lib.jea_quant_tables.restype = None
     lib.jea_write_header.argtypes = [vp, u16, u16, vp, vp]
@@ -187,12 +191,28 @@ class Context:
     def synchronize(self):
         self._check(self.lib.jea_synchronize(self.handle))
 
+    def set_scratch_budget(self, n_bytes):
+        self._check(self.lib.jea_set_scratch_budget(self.handle, int(n_bytes)))
+
+    def set_profiling(self, on):
+        self._check(self.lib.jea_set_profiling(self.handle, 1 if on else 0))
+
+    def last_phase_ms(self):
+        """Durations (ms) of the phases of the last encode / decode call made while profiling was on."""
+        ms = (ctypes.c_float * 8)()
+        n = ctypes.c_size_t(0)
+        self._check(self.lib.jea_last_phase_ms(self.handle, ms, 8, ctypes.byref(n)))
+        return [float(ms[i]) for i in range(n.value)]
+
     @property
     def stream_handle(self):
         return self.lib.jea_get_stream(self.handle)
 
     def to_device(self, array):
-        t = self.torch.from_numpy(np.ascontiguousarray(array)).to(self.tdev)
+        array = np.ascontiguousarray(array)
+        if not array.flags.writeable:   # e.g. a view of a bytes object: torch wants memory it may write to
+            array = array.copy()
+        t = self.torch.from_numpy(array).to(self.tdev)
         self.torch.cuda.synchronize(self.tdev)
         return t
 

@@ -72,6 +72,11 @@ struct jea_ctx {
     int32_t* d_status = nullptr;
     ComponentMode mode;   // jea_set_colour_mapper
     unsigned char* static_scratch = nullptr;   // this GPU's copy of `scratch`
+    // jea_set_profiling: events recorded at the phase boundaries of the last encode / decode call
+    size_t scratch_budget = (size_t)32 << 30;   // jea_set_scratch_budget
+    bool profiling = false;
+    hipEvent_t marks[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_marks = 0;   // marks recorded by the last profiled call
     // scratch, grown on demand and kept
     DeviceBuffer coefs, masks, len16, slots, tile_bits, tile_base, tile_ff, tile_ffbase, img_words, unstuffed;
     DeviceBuffer stage_in, stage_out, seg_offsets, out_offsets, out_sizes;
@@ -109,19 +114,36 @@ int fail(jea_ctx* ctx, int code, const std::string& msg) {
 
 int ensure(jea_ctx* ctx, DeviceBuffer& b, size_t bytes) {
     if (bytes <= b.bytes) return JEA_OK;
+    // the context's GPU must be current: hipMalloc takes whichever device is (several contexts on several
+    // GPUs may be driven from one thread)
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
     // work that still uses the old allocation must drain before it is freed
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (b.ptr) JEA_HIP(ctx, hipFree(b.ptr));
     b.ptr = nullptr;
     b.bytes = 0;
-    const size_t want = bytes + bytes / 8 + 256;
-    JEA_HIP(ctx, hipMalloc(&b.ptr, want));
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.ptr, want);
+    if (e == hipErrorOutOfMemory) {   // without the head-room
+        (void)hipGetLastError();
+        want = bytes;
+        e = hipMalloc(&b.ptr, want);
+    }
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        b.ptr = nullptr;
+        return fail(ctx, JEA_ERR_CAPACITY, "scratch buffer of " + std::to_string(bytes) +
+                                               " bytes does not fit the GPU's free memory; encode or decode fewer "
+                                               "images per call, or lower jea_set_scratch_budget");
+    }
+    JEA_HIP(ctx, e);
     b.bytes = want;
     return JEA_OK;
 }
 
 int ensure_pinned(jea_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_bytes) return JEA_OK;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->pinned) JEA_HIP(ctx, hipHostFree(ctx->pinned));
     ctx->pinned = nullptr;
@@ -133,6 +155,7 @@ int ensure_pinned(jea_ctx* ctx, size_t bytes) {
 }
 
 int ensure_pin_io(jea_ctx* ctx, size_t bytes) {
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
     if (bytes > ctx->pin_io_bytes) {
         JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->pin_io) JEA_HIP(ctx, hipHostFree(ctx->pin_io));
@@ -475,6 +498,8 @@ void jea_destroy(jea_ctx* ctx) {
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
     for (hipEvent_t e : ctx->piece_done)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->marks)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_huff) (void)hipFree(ctx->d_huff);
     if (ctx->d_decode) (void)hipFree(ctx->d_decode);
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
@@ -487,6 +512,7 @@ const char* jea_last_error(const jea_ctx* ctx) { return ctx ? ctx->error.c_str()
 
 int jea_set_stream(jea_ctx* ctx, void* hip_stream) {
     if (!ctx) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return JEA_OK;
@@ -502,8 +528,38 @@ int jea_set_colour_mapper(jea_ctx* ctx, int mapper) {
     return JEA_OK;
 }
 
+int jea_set_profiling(jea_ctx* ctx, int on) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    if (on)
+        for (hipEvent_t& e : ctx->marks)
+            if (!e) JEA_HIP(ctx, hipEventCreate(&e));
+    ctx->profiling = on != 0;
+    ctx->n_marks = 0;
+    return JEA_OK;
+}
+
+int jea_last_phase_ms(jea_ctx* ctx, float* ms, size_t capacity, size_t* n_phases) {
+    if (!ctx || !ms || !n_phases) return JEA_ERR_INVALID_ARG;
+    *n_phases = 0;
+    if (ctx->n_marks < 2) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_last_phase_ms: no profiled encode or decode call yet");
+    if (capacity < (size_t)ctx->n_marks - 1) return fail(ctx, JEA_ERR_CAPACITY, "jea_last_phase_ms: array too short");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    JEA_HIP(ctx, hipEventSynchronize(ctx->marks[ctx->n_marks - 1]));
+    for (int i = 0; i + 1 < ctx->n_marks; ++i) JEA_HIP(ctx, hipEventElapsedTime(&ms[i], ctx->marks[i], ctx->marks[i + 1]));
+    *n_phases = (size_t)ctx->n_marks - 1;
+    return JEA_OK;
+}
+
+int jea_set_scratch_budget(jea_ctx* ctx, size_t bytes) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    ctx->scratch_budget = bytes;
+    return JEA_OK;
+}
+
 int jea_synchronize(jea_ctx* ctx) {
     if (!ctx) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JEA_OK;
 }
@@ -786,18 +842,29 @@ int jea_entropy_encode(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, si
 static int enqueue_encode(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
                           const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_coefs, uint8_t* d_masks,
                           EntropyScratch sc, uint8_t* d_out, size_t out_capacity, uint64_t* d_offsets,
-                          uint64_t* d_sizes, int32_t* d_status) {
+                          uint64_t* d_sizes, int32_t* d_status, const uint64_t* d_prev_offset = nullptr,
+                          const uint64_t* d_prev_size = nullptr) {
     const size_t mcus = mcus_of(width, height);
     HeaderBytes hb{};
     jea_write_header(hb.b, width, height, lum_q, chr_q);
-    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs, d_status,
-                      d_masks, true, ctx->mode);
+    const bool timed = ctx->profiling;
+    ctx->n_marks = 0;
+    if (timed) JEA_HIP(ctx, hipEventRecord(ctx->marks[0], ctx->stream));
+    // the first pass of a call clears the status word; later passes (of a batch encoded in pieces) only raise it
+    launch_fdct_quant(ctx->stream, d_rgb, n_images, width, height, to_float_tables(lum_q, chr_q), d_coefs,
+                      d_prev_offset == nullptr ? d_status : nullptr, d_masks, true, ctx->mode);
     JEA_HIP(ctx, hipGetLastError());
+    if (timed) JEA_HIP(ctx, hipEventRecord(ctx->marks[1], ctx->stream));
     sc.chunk_masks = d_masks;
     sc.planar = true;
+    sc.marks = timed ? ctx->marks + 2 : nullptr;
     launch_entropy_encode(ctx->stream, d_coefs, n_images, mcus, ctx->d_huff, sc, hb, JEA_HEADER_BYTES, true, d_out,
-                          out_capacity, d_offsets, d_sizes, d_status);
+                          out_capacity, d_offsets, d_sizes, d_status, d_prev_offset, d_prev_size);
     JEA_HIP(ctx, hipGetLastError());
+    if (timed) {
+        JEA_HIP(ctx, hipEventRecord(ctx->marks[3], ctx->stream));
+        ctx->n_marks = 4;   // forward transform | bit strings | scans, pack and stuff
+    }
     return JEA_OK;
 }
 
@@ -808,26 +875,8 @@ static bool encode_args_ok(const uint8_t* d_rgb, size_t n_images, uint16_t width
            valid_dims(width, height) && tables_ok(lum_q, chr_q) && out_capacity >= JEA_HEADER_BYTES + 3;
 }
 
-int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
-                           const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
-                           uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
-    if (!ctx) return JEA_ERR_INVALID_ARG;
-    if (!encode_args_ok(d_rgb, n_images, width, height, lum_q, chr_q, d_out, out_capacity, d_offsets, d_sizes, d_status))
-        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch: invalid argument");
-    JEA_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t mcus = mcus_of(width, height);
-    int rc;
-    if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3))) return rc;
-    // scratch first: growing a buffer synchronises the stream, which must not happen between the launches
-    EntropyScratch sc;
-    if ((rc = prepare_entropy_scratch(ctx, n_images, mcus, out_capacity, sc))) return rc;
-    return enqueue_encode(ctx, d_rgb, n_images, width, height, lum_q, chr_q, (int16_t*)ctx->coefs.ptr,
-                          (uint8_t*)ctx->masks.ptr, sc, d_out, out_capacity, d_offsets, d_sizes, d_status);
-}
-
-// Bytes of `scratch` an encode of n_images pictures of `mcus` MCUs each takes: the same buffers that
-// jea_encode_batch_async keeps per context, each starting at a multiple of 256 bytes.
+// Bytes of scratch an encode of n_images pictures of `mcus` MCUs each takes: the same buffers that
+// the whole-encode entry points use (per context, or out of `scratch`), each starting at a multiple of 256 bytes.
 namespace {
 struct StaticLayout {
     size_t coefs, masks, len16, slots, tile_bits, tile_base, tile_ffbase, img_words, tile_ff8, total;
@@ -854,6 +903,39 @@ StaticLayout static_layout(size_t n_images, size_t mcus) {
     return l;
 }
 }  // namespace
+
+int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
+                           const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
+                           uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!encode_args_ok(d_rgb, n_images, width, height, lum_q, chr_q, d_out, out_capacity, d_offsets, d_sizes, d_status))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mcus = mcus_of(width, height);
+    // Scratch per image: coefficients (6 B/px) and the worst-case bit strings (53 248 B per tile, 9.9 B/px)
+    // dominate.  A batch whose scratch would exceed the context's budget goes through in passes of as many
+    // images as fit, one after the other on the stream with the same scratch; each pass continues the
+    // file offsets where the one before stopped, so the output is the same as that of one pass.
+    const size_t per_image = static_layout(1, mcus).total;
+    size_t pass = ctx->scratch_budget / per_image;
+    if (pass < 1) pass = 1;
+    if (pass > n_images) pass = n_images;
+    int rc;
+    if ((rc = ensure(ctx, ctx->coefs, pass * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->masks, pass * mcus * 3))) return rc;
+    // scratch first: growing a buffer synchronises the stream, which must not happen between the launches
+    EntropyScratch sc;
+    if ((rc = prepare_entropy_scratch(ctx, pass, mcus, out_capacity, sc))) return rc;
+    const size_t image_bytes = (size_t)3 * width * height;
+    for (size_t first = 0; first < n_images; first += pass) {
+        const size_t n = n_images - first < pass ? n_images - first : pass;
+        rc = enqueue_encode(ctx, d_rgb + first * image_bytes, n, width, height, lum_q, chr_q, (int16_t*)ctx->coefs.ptr,
+                            (uint8_t*)ctx->masks.ptr, sc, d_out, out_capacity, d_offsets + first, d_sizes + first, d_status,
+                            first ? d_offsets + first - 1 : nullptr, first ? d_sizes + first - 1 : nullptr);
+        if (rc) return rc;
+    }
+    return JEA_OK;
+}
 
 size_t jea_static_scratch_needed(size_t n_images, uint16_t width, uint16_t height) {
     if (n_images == 0 || !valid_dims(width, height)) return 0;
@@ -899,6 +981,7 @@ int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16
     if (!ctx) return JEA_ERR_INVALID_ARG;
     if (!h_offsets || !h_sizes || n_images == 0)
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = ensure(ctx, ctx->out_offsets, n_images * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->out_sizes, n_images * sizeof(uint64_t)))) return rc;
@@ -1123,9 +1206,15 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.ctx_keys = (unsigned long long*)ctx->ctx_keys.ptr;
     sc.ctx_vals = (uint32_t*)ctx->ctx_vals.ptr;
     sc.ctx_slots = kContextSlots;
+    ctx->n_marks = 0;
+    if (ctx->profiling) {
+        JEA_HIP(ctx, hipEventRecord(ctx->marks[0], ctx->stream));
+        sc.marks = ctx->marks + 1;
+    }
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
                                        ctx->d_status, follow_up, report));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) ctx->n_marks = 5;   // unstuffing | synchronisation rounds | scan and write pass | follow-up
     if (with_headers && (rc = headers_ok())) return rc;
     if (report->unsettled != 0)
         JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs, ctx->d_status,

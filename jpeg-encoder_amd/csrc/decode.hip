@@ -1041,8 +1041,11 @@ struct DecodeRun {
     hipError_t first_pass(const std::function<void()>& follow_up, DecodeReport* report) const {
         sync_round(1, sc.changed + 0, false);
         sync_round(0, sc.changed + 1, false);
+        if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[1], s);
         scan_and_write(sc.changed + 2);
+        if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[2], s);
         if (follow_up) follow_up();
+        if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[3], s);
         report_kernel<<<1, 1, 0, s>>>(sc.changed + 2, d_status, report);
         return hipGetLastError();
     }
@@ -1102,6 +1105,7 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
                                                                  sc.chunk_base, sc.img_drops, sc.ubase, sc.ustream);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[0], s);
     switch (p.sub_words) {
         case kSubWordsSmall:
             return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);

@@ -134,6 +134,13 @@ struct ImageLevel {
     uint64_t capacity;
     uint32_t fixed_bytes;   // mode 2: header + EOI bytes
     int32_t* status;
+    // mode 2, a batch encoded in several passes: offset and size of the file before this pass's first one
+    // (null: this pass's files start at offset 0)
+    const uint64_t* prev_offset = nullptr;
+    const uint64_t* prev_size = nullptr;
+    __device__ uint64_t first_offset() const {
+        return prev_offset != nullptr ? (*prev_offset + *prev_size + 63) / 64 * 64 : 0;
+    }
 };
 
 __device__ __forceinline__ uint64_t unstuffed_bytes(uint64_t bits) { return (bits + 7) >> 3; }
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(1024) void scan_images_kernel(uint32_t n_images, co
     __shared__ uint64_t wave_sum[16];
     __shared__ uint64_t carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
+    if (threadIdx.x == 0) carry_s = lvl.mode == 2 ? lvl.first_offset() : 0;
     __syncthreads();
     for (uint32_t i0 = 0; i0 < n_images; i0 += 1024) {
         const uint32_t i = i0 + threadIdx.x;
@@ -581,9 +588,10 @@ __global__ __launch_bounds__(1024) void scan_tiles_ff_kernel(const uint32_t* __r
         img_ff[img] = carry_ff;
         if (gridDim.x == 1) {
             const uint64_t size = unstuffed_bytes(carry_bits) + carry_ff + lvl.fixed_bytes;
-            lvl.base_out[0] = 0;
+            const uint64_t at = lvl.first_offset();
+            lvl.base_out[0] = at;
             lvl.size_out[0] = size;
-            if (size > lvl.capacity) atomicExch(lvl.status, JEA_ERR_CAPACITY);
+            if (at + size > lvl.capacity) atomicExch(lvl.status, JEA_ERR_CAPACITY);
         }
     }
 }
@@ -806,7 +814,8 @@ void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, 
 void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
                            const HuffTables* d_huff, const EntropyScratch& sc, const HeaderBytes& header,
                            int header_len, bool with_eoi, uint8_t* d_out, size_t out_capacity, uint64_t* d_offsets,
-                           uint64_t* d_sizes, int32_t* d_status) {
+                           uint64_t* d_sizes, int32_t* d_status, const uint64_t* d_prev_offset,
+                           const uint64_t* d_prev_size) {
     const uint32_t nbc = (uint32_t)(mcus_per_image * 3);
     const uint32_t n_tiles = tiles_per_image(mcus_per_image);
     const dim3 grid(n_tiles, (unsigned)n_images);
@@ -822,7 +831,8 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
         tile_bits_kernel<false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.chunk_masks, sc.mode,
                                                              sc.len16, sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8,
                                                              d_status);
-    if (n == 1 && n_tiles <= kFoldTiles) {
+    if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[0], s);
+    if (n == 1 && n_tiles <= kFoldTiles && d_prev_offset == nullptr) {
         // One image with few tiles: every workgroup sums over the tiles before it, which is cheaper than a
         // single-workgroup scan launched in between.
         pack_stuff_kernel<true><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits,
@@ -832,6 +842,8 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
         return;
     }
     ImageLevel lvl{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
+    lvl.prev_offset = d_prev_offset;
+    lvl.prev_size = d_prev_size;
     scan_tiles_ff_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, (const uint4*)sc.tile_ff8, n_tiles, sc.tile_base,
                                             sc.tile_ffbase, sc.img_bits, sc.img_ff, lvl);
     if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, lvl);

@@ -137,6 +137,8 @@ struct EntropyScratch {
     size_t unstuffed_capacity;
     uint32_t* tile_ff8;     // [n_images][n_tiles] x 16 bytes: 0xFF bytes a tile owns for each of the eight bit
                             // alignments it may get, as 16-bit counts
+    hipEvent_t* marks = nullptr;   // timing marks (null = none): launch_entropy_encode records marks[0] after the
+                                   // bit-string kernel; the caller records what comes before and after
 };
 
 // d_status_to_clear (may be null): status word of the encode pass this launch opens; the kernel zeroes it.
@@ -155,10 +157,13 @@ void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, 
                         ComponentMode mode = ComponentMode{});
 
 // bit-length pass -> scans -> pack -> stuff.  header_len is 0 or 607; with_eoi appends FFD9.
+// d_prev_offset / d_prev_size (null, or both given): a batch encoded in several passes -- offset and size (device
+// memory, written by the pass before) of the file after which this pass's files continue at 64-byte steps.
 void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
                            const HuffTables* d_huff, const EntropyScratch& sc, const HeaderBytes& header,
                            int header_len, bool with_eoi, uint8_t* d_out, size_t out_capacity,
-                           uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
+                           uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status,
+                           const uint64_t* d_prev_offset = nullptr, const uint64_t* d_prev_size = nullptr);
 
 // Stripe encode in two steps around the exchange of the stripes' bit totals:
 // bits: block bit strings (DC chain continued from st.initial_dc), per-tile scan,
@@ -205,6 +210,9 @@ struct DecodeScratch {
     ComponentMode mode;
     uint32_t* out_records;   // null: coefficients go out as [block][64]; else they go out as block records
                              // [n][mcus*3] plus chunk planes, see launch_idct_dequant
+    hipEvent_t* marks = nullptr;   // timing marks (null = none): launch_entropy_decode records marks[0] after
+                                   // unstuffing, [1] after the two synchronisation rounds, [2] after scan and
+                                   // write pass, [3] after follow_up
 };
 
 // What the decoder tells the host, in host memory that the GPU can write (hipHostMalloc).

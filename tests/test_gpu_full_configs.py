@@ -1,0 +1,120 @@
+"""The benchmark configurations at their full sizes, on one GPU, against the recorded reference hashes and the oracle.
+
+  C3  1024 x 1920x1080 at q=90 in one encode call
+  C4  one 16384x16384 image at q=75: on one context, and as 8 stripes of 2048 rows on 8 contexts
+  C5  1024 x 1920x1080 JPEGs at q=50 in one decode call
+(C1 and C2, 512x512 and 3840x2160, are rows of test_golden_hashes.)  Bar: bit-exact.
+"""
+import concurrent.futures
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_FRAMES, FW, FH = 1024, 1920, 1080
+THREADS = 16   # the oracle is plain C behind ctypes (the GIL is released): one image per thread
+
+
+def _golden_row(w, h, q, mode):
+    rows = json.load(open(os.path.join(GOLDEN, "reference_hashes.json")))["rows"]
+    return next(r for r in rows if (r["w"], r["h"], r["q"], r["mode"]) == (w, h, q, mode))
+
+
+@pytest.fixture(scope="module")
+def gigapixel(po):
+    return po.gen_image(16384, 16384, 0, 1234)
+
+
+def test_c4_gigapixel_on_one_context(ctx, po, jea, gigapixel):
+    import torch
+
+    w = h = 16384
+    r = _golden_row(w, h, 75, 0)
+    lum, chrom = jea.binding.quant_tables(75)
+    d_rgb = ctx.to_device(gigapixel.reshape(-1))
+    out, off, size = ctx.encode_batch(d_rgb, 1, w, h, lum, chrom, capacity=64 << 20)
+    jpeg = out[: int(size[0])].cpu().numpy().tobytes()
+    assert len(jpeg) == r["jpeg_bytes"] and po.fnv(jpeg) == r["jpeg_fnv"]
+    del d_rgb
+    d_jpeg = ctx.to_device(np.frombuffer(jpeg, np.uint8))
+    rgb = ctx.decode_batch(d_jpeg, [0], [len(jpeg)], w, h, lum, chrom)
+    assert po.fnv(rgb.cpu().numpy()) == r["rgb_fnv"]
+    del rgb, out
+    torch.cuda.empty_cache()
+
+
+def test_c4_gigapixel_as_eight_stripes(jea, po, gigapixel):
+    """The C4 partition: 8 stripes of 2048 rows, each on a context of its own, through the HIP stripe steps."""
+    stripes = importlib.import_module("jpeg-encoder_amd.stripes")
+    w = h = 16384
+    r = _golden_row(w, h, 75, 0)
+    lum, chrom = jea.binding.quant_tables(75)
+    rows = stripes.stripe_rows(h, 8)
+    assert rows == [(i * 2048, (i + 1) * 2048) for i in range(8)]
+    ctxs = [jea.Context(0) for _ in rows]
+    try:
+        d_rgb = ctxs[0].to_device(gigapixel.reshape(-1))
+        backends = [stripes.HipBackend(c, d_rgb[y0 * w * 3: y1 * w * 3], w, y1 - y0, lum, chrom)
+                    for c, (y0, y1) in zip(ctxs, rows)]
+        jpeg = stripes.encode_in_process(backends, w, h)
+        assert len(jpeg) == r["jpeg_bytes"] and po.fnv(jpeg) == r["jpeg_fnv"]
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def _frame(po, i):
+    # distinct sources: smooth pictures with their own noise, and every 64th one uniform noise
+    return po.gen_image(FW, FH, 1 if i % 64 == 63 else 0, 1234 + i)
+
+
+@pytest.fixture(scope="module")
+def frames(po):
+    with concurrent.futures.ThreadPoolExecutor(THREADS) as pool:
+        return np.stack(list(pool.map(lambda i: _frame(po, i), range(N_FRAMES))))
+
+
+def test_c3_batch_of_1024_frames_in_one_call(ctx, po, jea, frames):
+    import torch
+
+    q = 90
+    lum, chrom = jea.binding.quant_tables(q)
+    with concurrent.futures.ThreadPoolExecutor(THREADS) as pool:
+        want = list(pool.map(lambda i: po.encode(frames[i], q), range(N_FRAMES)))
+    assert po.fnv(want[0]) == _golden_row(FW, FH, q, 0)["jpeg_fnv"]        # frame 0 is the recorded picture
+    d_rgb = ctx.to_device(frames.reshape(-1))
+    cap = sum(len(f) for f in want) + 64 * N_FRAMES
+    out, off, size = ctx.encode_batch(d_rgb, N_FRAMES, FW, FH, lum, chrom, capacity=cap)
+    del d_rgb
+    assert np.array_equal(size, np.array([len(f) for f in want], dtype=size.dtype))
+    host = out.cpu().numpy()
+    del out
+    torch.cuda.empty_cache()
+    for i in range(N_FRAMES):                                                # every file, byte for byte
+        assert host[int(off[i]): int(off[i] + size[i])].tobytes() == want[i], i
+
+
+def test_c5_decode_of_1024_frames_in_one_call(ctx, po, jea, frames):
+    import torch
+
+    q = 50
+    lum, chrom = jea.binding.quant_tables(q)
+    d_rgb = ctx.to_device(frames.reshape(-1))
+    out, off, size = ctx.encode_batch(d_rgb, N_FRAMES, FW, FH, lum, chrom, capacity=N_FRAMES * (3 << 20))
+    del d_rgb
+    host = out.cpu().numpy()
+    files = [host[int(off[i]): int(off[i] + size[i])].tobytes() for i in range(N_FRAMES)]
+    assert po.fnv(files[0]) == _golden_row(FW, FH, q, 0)["jpeg_fnv"]
+    rgb = ctx.decode_batch(out, off, size, FW, FH, lum, chrom)
+    got = rgb.cpu().numpy().reshape(N_FRAMES, FH, FW, 3)
+    del rgb, out
+    torch.cuda.empty_cache()
+    assert po.fnv(got[0].reshape(-1)) == _golden_row(FW, FH, q, 0)["rgb_fnv"]
+    with concurrent.futures.ThreadPoolExecutor(THREADS) as pool:
+        same = list(pool.map(lambda i: np.array_equal(got[i], po.decode(files[i], FW, FH, q)), range(N_FRAMES)))
+    assert all(same), [i for i, s in enumerate(same) if not s][:8]

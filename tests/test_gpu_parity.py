@@ -260,7 +260,7 @@ def test_golden_hashes(ctx, po, jea):
     """The whole-file hashes recorded from the reference itself (tests/golden/reference_hashes.json)."""
     rows = json.load(open(os.path.join(GOLDEN, "reference_hashes.json")))["rows"]
     for r in rows:
-        if r.get("slow") or r["w"] * r["h"] > 3840 * 2160:
+        if r.get("slow"):   # the 16384x16384 row: test_gpu_full_configs.py
             continue
         w, h, q = r["w"], r["h"], r["q"]
         rgb = po.gen_image(w, h, r["mode"], 1234)
@@ -631,3 +631,78 @@ def test_host_buffers_large_enough_for_the_threaded_copy(ctx, po, jea):
         want = po.encode(rgb, 90)
         assert bytes(ctx.encode_host(rgb, lum, chrom)) == want, (w, h)
         assert np.array_equal(ctx.decode_host(want, w, h, lum, chrom), po.decode(want, w, h, 90)), (w, h)
+
+
+def test_encode_batch_in_passes_under_a_scratch_budget(jea, po):
+    """A batch whose scratch exceeds the context's budget is encoded in passes; files, offsets and sizes are
+    those of a single pass."""
+    import torch
+
+    b = jea.binding
+    n, w, h, quality = 7, 200, 120, 80
+    lum, chrom = b.quant_tables(quality)
+    imgs = np.stack([po.gen_image(w, h, i % 2, 40 + i) for i in range(n)])
+    want = [po.encode(imgs[i], quality) for i in range(n)]
+    for budget in (b.static_scratch_needed(2, w, h) + 1000, 1):          # passes of 2 images; of 1 image
+        c = jea.Context(0)
+        try:
+            c.set_scratch_budget(budget)
+            d_rgb = c.to_device(imgs.reshape(-1))
+            cap = sum(len(f) + 64 for f in want)
+            out = torch.full((cap,), 0xA5, dtype=torch.uint8, device=c.tdev)
+            _, off, size = c.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=cap, d_out=out)
+            host = out.cpu().numpy()
+            at = 0
+            for i in range(n):
+                assert int(off[i]) == at and int(size[i]) == len(want[i]), (budget, i)
+                assert host[at: at + len(want[i])].tobytes() == want[i], (budget, i)
+                at = (at + len(want[i]) + 63) // 64 * 64
+            # one byte less than needed: the pass that does not fit reports it
+            short = int(off[n - 1]) + int(size[n - 1]) - 1
+            with pytest.raises(b.JeaError) as e:
+                c.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=short, d_out=out[:short])
+            assert e.value.code == 3
+        finally:
+            c.close()
+
+
+def test_phase_timing(ctx, po, jea):
+    b = jea.binding
+    w, h, quality = 640, 480, 75
+    lum, chrom = b.quant_tables(quality)
+    rgb = po.gen_image(w, h, 0, 3)
+    with pytest.raises(b.JeaError):
+        ctx.last_phase_ms()                       # nothing profiled yet
+    ctx.set_profiling(True)
+    try:
+        out, off, size = ctx.encode_batch(ctx.to_device(rgb.reshape(-1)), 1, w, h, lum, chrom)
+        enc = ctx.last_phase_ms()
+        assert len(enc) == 3 and all(0.0 < t < 50.0 for t in enc)
+        jpeg = out[: int(size[0])].cpu().numpy().tobytes()
+        assert jpeg == po.encode(rgb, quality)      # timing marks do not change the result
+        got = ctx.decode_batch(ctx.to_device(np.frombuffer(jpeg, np.uint8)), [0], [len(jpeg)], w, h, lum, chrom)
+        dec = ctx.last_phase_ms()
+        assert len(dec) == 4 and all(0.0 < t < 50.0 for t in dec)
+        assert np.array_equal(got.cpu().numpy().reshape(h, w, 3), po.decode(jpeg, w, h, quality))
+    finally:
+        ctx.set_profiling(False)
+
+
+def test_contexts_on_two_gpus_from_one_thread(jea, po):
+    """A context's buffers land on its own GPU whichever device is current (needs two GPUs)."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU")
+    b = jea.binding
+    w, h, quality = 328, 200, 75
+    lum, chrom = b.quant_tables(quality)
+    rgb = po.gen_image(w, h, 1, 9)
+    c0, c1 = jea.Context(0), jea.Context(1)          # device 1 is current after this
+    try:
+        for c in (c0, c1, c0):
+            out, off, size = c.encode_batch(c.to_device(rgb.reshape(-1)), 1, w, h, lum, chrom)
+            assert out[: int(size[0])].cpu().numpy().tobytes() == po.encode(rgb, quality)
+    finally:
+        c0.close()
+        c1.close()

@@ -1,0 +1,74 @@
+"""The stripe protocol and the HIP stripe kernels together, across processes: every rank is a process of its own
+with its own context (all on GPU 0 here; one per GPU in production), the exchanges go over torch.distributed
+(gloo in this test, RCCL in bench.py --config c4), and rank 0 gathers the segments.  The file must be the
+serial encoder's, byte for byte."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _image(po, w, h):
+    rgb = po.gen_image(w, h, 0, 31)
+    rgb[h // 3: h // 3 + h // 4, w // 5: w // 5 + w // 2] = po.gen_image(w // 2, h // 4, 1, 32)   # a noisy patch across stripe borders
+    return rgb
+
+
+def _worker(rank, world, port, w, h, quality, out):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import pyoracle as po
+
+    pkg = importlib.import_module("jpeg-encoder_amd")
+    stripes = importlib.import_module("jpeg-encoder_amd.stripes")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ctx = pkg.Context(0)
+    lum, chrom = pkg.binding.quant_tables(quality)
+    y0, y1 = stripes.stripe_rows(h, world)[rank]
+    d_rgb = ctx.to_device(_image(po, w, h)[y0:y1].reshape(-1))
+    backend = stripes.HipBackend(ctx, d_rgb, w, y1 - y0, lum, chrom)
+    seg = stripes.encode_stripe(backend, rank, world, stripes.dist_all_gather(dist), w, h)
+    whole = stripes.gather_segments(seg, dist)
+    if rank == 0:
+        out.put(whole)
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,quality", [(2, 1024, 768, 75), (3, 520, 333, 90)])
+def test_hip_stripes_across_processes(po, world, w, h, quality):
+    port = _free_port()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, w, h, quality, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        whole = q.get(timeout=100)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    assert whole == po.encode(_image(po, w, h), quality)
