@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
-"""Headline benchmark: baseline-JPEG encode throughput (MPix/s, q=75) on MI355X.
+"""Benchmarks of the baseline-JPEG hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
-One step = one encode of `--batch` (default 1) device-resident 3840x2160 RGB
-images at q=75 through the whole hot path (fused colour+FDCT+quantise+zigzag
-kernel, bit-length pass, scans, pack, byte stuffing, header and EOI); input and
-output stay in HBM.  For N > 1 the driver launches one rank per GPU with
-torch.distributed.run; images are sharded by rank, there is no data-path
-collective, and the reported value is all ranks' pixels over the slowest rank's
-time (weak scaling).
+--config names the workload (the numbering of BASELINE.json's configs; c1 is the reference's own CPU case):
+  c2 (default)  one 3840x2160 image encoded at q=75 per step -- the configuration the metric is quoted on.
+                Steps alternate over `--streams` contexts and over a pool of distinct input images that is
+                larger than the 256 MB Infinity Cache, so every step reads its picture from HBM.
+  c3            1024 frames of 1920x1080 at q=90, sharded by image over the ranks; a step encodes the rank's
+                share in one call.
+  c4            one 16384x16384 image at q=75 as MCU-row stripes, one stripe per rank; a step is the whole
+                protocol: transform, exchange of the DC predictors, bit strings, exchange of the bit counts,
+                pack and stuff, gather of the segments on rank 0 (RCCL between GPUs).
+  c5            1024 JPEG files of 1920x1080 at q=50 decoded, sharded by image; a step decodes the rank's share.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run.  There is no data-path collective
+except c4's exchanges; the reported value is all ranks' pixels over the slowest rank's time (weak scaling for
+c2, strong for c3-c5, whose total work is fixed).
+
+Timing: after an untimed ramp and W warm-up steps, regions of exactly K steps each are timed, every one
+bracketed by a barrier and a device synchronisation on both sides; as many regions as fit 50 ms (one, when K
+steps take that long).  The value is taken from the median region (slowest rank of each region).
 
 The JSON line also carries
-  roofline      the fused FDCT kernel's algorithmic bytes (9 B/px) over its
-                average launch duration, measured with HIP events on the
-                library's stream, against the 8 TB/s HBM peak
-  cpu_baseline  the CPU restatement of the reference encoder (oracle/), one
-                thread, timed on this host on a bounded sample (rank 0, N=1)
+  roofline      the dominant kernel's algorithmic bytes over its measured duration against the 8 TB/s HBM peak,
+                what actually binds it (`bound`), and for the forward kernel the vector-instruction issue figures
+  cpu_baseline  the CPU restatement of the reference encoder (oracle/), one thread, on a bounded sample, plus
+                the same work image-parallel on the host's cores (rank 0, N=1)
 """
 import argparse
+import concurrent.futures
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -30,9 +41,16 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-W, H, QUALITY = 3840, 2160, 75
 HBM_PEAK_GBS = 8000.0
-K1_BYTES_PER_PIXEL = 9.0  # 3 B RGB read + 3 x int16 coefficient write
+K1_BYTES_PER_PIXEL = 9.0      # forward kernel: 3 B RGB read + 3 x int16 coefficients written
+INVERSE_BYTES_PER_PIXEL = 9.0  # inverse kernel: 6 B coefficients read + 3 B RGB written
+CPU_THREADS = 16              # the GPU box gives a one-GPU job 16 host cores
+MIN_TIMED_SECONDS = 0.05
+# vector-instruction issue cost on this chip (tools/valu_rates.hip, best of five to eight waves per SIMD): f32 add / mul / fma on
+# vector-register or literal operands; everything else (conversions, fract, compares, perm, scalar operands)
+VALU_FULL_RATE_NS = 1.03
+VALU_HALF_RATE_NS = 1.72
+SIMDS = 1024
 
 
 def photo_like_image(width, height, seed):
@@ -49,207 +67,607 @@ def photo_like_image(width, height, seed):
     return np.stack([np.clip(128 + 48 * c / c.std(), 0, 255) for c in chans], axis=-1).astype(np.uint8)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class Job:
+    """Process group, device and the timing protocol shared by all configurations."""
+
+    def __init__(self, args):
+        import torch
+
+        self.args = args
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, self.world), file=sys.stderr)
+        self.dist = None
+        n_devices = torch.cuda.device_count()
+        # One rank per GPU.  JEA_DIST_BACKEND=gloo rehearses the multi-process flow on a box with fewer GPUs
+        # than ranks (ranks then share devices); the measured runs use RCCL ("nccl").
+        self.backend = os.environ.get("JEA_DIST_BACKEND", "nccl")
+        if self.backend == "nccl" and self.local_rank >= n_devices:
+            raise SystemExit("bench: rank %d has no GPU of its own (%d visible)" % (self.local_rank, n_devices))
+        self.device_index = self.local_rank % max(1, n_devices)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            torch.cuda.set_device(self.device_index)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.device_index))
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        self.pkg = importlib.import_module("jpeg-encoder_amd")
+        self.binding = self.pkg.binding
+        self.dev = torch.device("cuda", self.device_index)
+        self.comm_device = self.dev if self.backend == "nccl" else "cpu"
+
+    def barrier(self, sync):
+        if self.dist is not None:
+            self.dist.barrier()
+        sync()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.comm_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value):
+        if self.dist is None:
+            return value
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.comm_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def timed(self, step, sync, steps=None, warmup=None, ramp=None):
+        """Returns (seconds of the median region of `steps` steps, all region times)."""
+        steps = self.args.steps if steps is None else steps
+        warmup = self.args.warmup if warmup is None else warmup
+        ramp = self.args.ramp_seconds if ramp is None else ramp
+        # A parity gate before this left the GPU idle while the CPU encoded; its clocks take some milliseconds
+        # of load to come back up.  Untimed steps until the ramp time has passed, then the W warm-up steps.
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < ramp:
+            for _ in range(min(50, max(1, steps))):
+                step()
+            sync()
+        for _ in range(warmup):
+            step()
+        regions = []
+        want = 1
+        while len(regions) < want:
+            self.barrier(sync)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            sync()
+            self.torch.cuda.synchronize(self.dev)
+            regions.append(self.max_over_ranks(time.perf_counter() - t0))   # the job's time: the slowest rank's
+            if len(regions) == 1:
+                want = int(min(60, max(1, math.ceil(MIN_TIMED_SECONDS / max(regions[0], 1e-9)))))
+        self.barrier(sync)
+        ordered = sorted(regions)
+        return ordered[len(ordered) // 2], regions
+
+    def finish(self, out):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+        if self.rank == 0:
+            print(json.dumps(out))
+
+
+def region_stats(regions):
+    ordered = sorted(regions)
+    return {"timed_regions": len(regions), "region_ms_min_median_max":
+            [round(ordered[0] * 1e3, 4), round(ordered[len(ordered) // 2] * 1e3, 4), round(ordered[-1] * 1e3, 4)]}
+
+
+def pmc_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def cpu_encode_baseline(po, images, quality, n_single, threads):
+    """The oracle on this host: one thread (what the reference does), then one image per thread."""
+    w, h = images[0].shape[1], images[0].shape[0]
+    t0 = time.perf_counter()
+    for i in range(n_single):
+        po.encode(images[i % len(images)], quality)
+    single = n_single * w * h / (time.perf_counter() - t0) / 1e6
+    n_all = 2 * threads
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(threads) as pool:
+        list(pool.map(lambda i: po.encode(images[i % len(images)], quality), range(n_all)))
+    allc = n_all * w * h / (time.perf_counter() - t0) / 1e6
+    return {"value": round(single, 2), "unit": "MPix/s", "cores": 1, "kind": "port",
+            "sample": "%d encodes of %dx%d q=%d synthetic image(s), one thread, oracle/jpeg_oracle.c (a restatement of "
+                      "the reference that tabulates its cosines; the reference itself is single-threaded)"
+                      % (n_single, w, h, quality),
+            "all_cores": {"value": round(allc, 2), "unit": "MPix/s", "cores": threads, "cpu_model": cpu_model(),
+                          "host_cpus_visible": os.cpu_count(),
+                          "sample": "%d encodes, one image per thread on %d threads" % (n_all, threads)}}
+
+
+def forward_kernel_roofline(job, ctx, d_rgb_pool, w, h, lum, chrom, images_per_launch=1):
+    """Forward kernel alone, back to back on the library's stream, timed with HIP events on that stream."""
+    torch, binding = job.torch, job.binding
+    ext = torch.cuda.ExternalStream(ctx.stream_handle, device=job.dev)
+    n = images_per_launch
+    mcus = binding.n_mcu(w, h)
+    d_coefs = torch.empty(8 * n * mcus * 192, dtype=torch.int16, device=job.dev)
+    d_masks = torch.empty(8 * n * mcus * 3, dtype=torch.uint8, device=job.dev)
+
+    def launches(images, reps):
+        with torch.cuda.stream(ext):
+            for i in range(3):
+                ctx.fdct_quant_planar_async(d_rgb_pool[i % len(d_rgb_pool)], images, w, h, lum, chrom, d_coefs, d_masks)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(reps):
+                ctx.fdct_quant_planar_async(d_rgb_pool[i % len(d_rgb_pool)], images, w, h, lum, chrom, d_coefs, d_masks)
+            e1.record()
+        ctx.synchronize()
+        return e0.elapsed_time(e1) / reps   # ms
+
+    one = launches(n, 60)
+    k_bytes = K1_BYTES_PER_PIXEL * n * w * h
+    roof = {"kernel": "fdct_quant_kernel", "achieved": round(k_bytes / (one * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(k_bytes / (one * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "avg_launch_us": round(one * 1e3, 2), "algorithmic_bytes_per_launch": int(k_bytes)}
+    # The same kernel with eight times the work per launch (the pool's images side by side, when the pool is one
+    # buffer of at least that many): the difference is the cost of one more step's worth of work once the
+    # launch's fixed latency (first and last workgroups running on a half-empty GPU) is paid.
+    whole = getattr(d_rgb_pool, "whole", None)
+    if whole is not None and whole.numel() >= 8 * n * 3 * w * h:
+        with torch.cuda.stream(ext):
+            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2):
+                ctx.fdct_quant_planar_async(whole, 8 * n, w, h, lum, chrom, d_coefs, d_masks)
+            e2.record()
+            for _ in range(12):
+                ctx.fdct_quant_planar_async(whole, 8 * n, w, h, lum, chrom, d_coefs, d_masks)
+            e3.record()
+        ctx.synchronize()
+        eight = e2.elapsed_time(e3) / 12
+        steady = max((eight - one) / 7, 1e-6)
+        roof["marginal_us_per_step_of_work"] = round(steady * 1e3, 2)
+        roof["marginal_frac"] = round(k_bytes / (steady * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return roof, one
+
+
+class ImagePool(list):
+    """Device-resident images: pool[i] is image i; pool.whole is the one buffer that holds them back to back."""
+
+
+def make_pool(ctx, images):
+    import numpy as np
+
+    whole = ctx.to_device(np.ascontiguousarray(images).reshape(-1))
+    per = images[0].size
+    pool = ImagePool(whole[i * per: (i + 1) * per] for i in range(len(images)))
+    pool.whole = whole
+    return pool
+
+
+# ---------------------------------------------------------------------------------------------------------
+def config_c2(job):
+    import numpy as np
+    import pyoracle as po  # generator + checker only; nothing timed on the GPU side calls it
+
+    args, torch, binding = job.args, job.torch, job.binding
+    W, H, QUALITY = 3840, 2160, 75
+    ctxs = [job.pkg.Context(job.device_index) for _ in range(max(1, args.streams))]
+    ctx = ctxs[0]
+    lum, chrom = binding.quant_tables(QUALITY)
+    batch = args.batch
+
+    def generator(mode):
+        return (lambda seed: photo_like_image(W, H, seed)) if mode == 2 else (lambda seed: po.gen_image(W, H, mode, seed))
+
+    def capacity(mode):
+        return batch * (3 * W * H // 2 + (1 << 20)) if mode == 0 else batch * binding.max_jpeg_bytes(W, H)
+
+    def measure(mode, pool_images, steps, warmup, ramp, check):
+        """Encode rate (MPix/s) with steps alternating over the contexts and over the pool of input images."""
+        gen = generator(mode)
+        n_pool = max(1, pool_images // batch) * batch
+        with concurrent.futures.ThreadPoolExecutor(8) as tp:
+            imgs = np.stack(list(tp.map(lambda i: gen(1234 + job.rank * 1000 + i), range(n_pool))))
+        pool = make_pool(ctx, imgs)
+        groups = [pool.whole[g * batch * 3 * W * H: (g + 1) * batch * 3 * W * H] for g in range(n_pool // batch)]
+        cap = capacity(mode)
+        outs = [dict(out=torch.empty(cap, dtype=torch.uint8, device=job.dev),
+                     offsets=torch.zeros(batch, dtype=torch.int64, device=job.dev),
+                     sizes=torch.zeros(batch, dtype=torch.int64, device=job.dev),
+                     status=torch.zeros(16, dtype=torch.int32, device=job.dev)) for _ in ctxs]
+        torch.cuda.synchronize(job.dev)
+        turn = [0]
+
+        def step():
+            i = turn[0]
+            turn[0] += 1
+            o = outs[i % len(ctxs)]
+            ctxs[i % len(ctxs)].encode_batch_async(groups[i % len(groups)], batch, W, H, lum, chrom, o["out"], o["offsets"],
+                                                   o["sizes"], o["status"])
+
+        def sync_all():
+            for c in ctxs:
+                c.synchronize()
+
+        size0 = None
+        if check:
+            # parity gate before timing: files of pool images must equal the oracle's, byte for byte
+            for g in sorted(set([0, len(groups) - 1])):
+                turn[0] = g
+                step()
+                sync_all()
+                o = outs[g % len(ctxs)]
+                assert int(o["status"][0].item()) == 0, "encode reported status %d" % int(o["status"][0].item())
+                off, size = int(o["offsets"][0].item()), int(o["sizes"][0].item())
+                if o["out"][off: off + size].cpu().numpy().tobytes() != po.encode(imgs[g * batch], QUALITY):
+                    raise SystemExit("bench: GPU JPEG differs from the oracle's; refusing to report a number")
+                if g == 0:
+                    size0 = size
+            turn[0] = 0
+        seconds, regions = job.timed(step, sync_all, steps, warmup, ramp)
+        assert all(int(o["status"][0].item()) == 0 for o in outs)
+        rate = job.sum_over_ranks(steps * batch * W * H) / seconds / 1e6
+        return rate, seconds, regions, pool, imgs, size0
+
+    value, seconds, regions, pool, imgs, size0 = measure(args.mode, args.pool, args.steps, args.warmup, args.ramp_seconds, True)
+
+    out = {
+        "metric": "encode MPix/s (q=75)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic %s RGB8 (seeds 1234+), %d distinct images per rank resident in HBM (%d MB, more than the "
+                "256 MB Infinity Cache), read in rotation" % (("smooth", "noise", "photo-like")[args.mode], len(pool),
+                                                              len(pool) * 3 * W * H >> 20),
+        "config": {"workload": "single 3840x2160 RGB image encode at q=75 per step" if batch == 1 else
+                   "%d x 3840x2160 RGB images encoded at q=75 per step" % batch,
+                   "images_per_step": batch, "width": W, "height": H, "quality": QUALITY,
+                   "jpeg_bytes_image0": size0, "byte_identical_to_oracle": True,
+                   "streams": len(ctxs), "input_pool_images": len(pool), "sharding": "images by rank, no collective",
+                   "untimed_ramp_seconds_before_warmup": args.ramp_seconds, **region_stats(regions)},
+    }
+
+    if job.world == 1 and not args.quick:
+        # ---- the same measurement in other settings, each labelled; none of them is `value` ----
+        others = {}
+        lat_ctxs, ctxs[:] = ctxs[:], ctxs[:1]                     # one context: images strictly one after the other
+        r, s, _, _, _, _ = measure(args.mode, args.pool, max(50, args.steps // 4), 20, 0.05, False)
+        others["one_stream_latency"] = {"MPix/s": round(r, 1), "us_per_image": round(s / max(50, args.steps // 4) * 1e6 / batch, 2),
+                                        "note": "one context, every image waits for the one before"}
+        ctxs[:] = lat_ctxs
+        r, _, _, _, _, _ = measure(args.mode, batch, max(50, args.steps // 4), 20, 0.05, False)
+        others["input_cached"] = {"MPix/s": round(r, 1), "note": "every step encodes the same image (it stays in the Infinity Cache)"}
+        for mode, name, n_pool in ((2, "photo_like", 2), (1, "noise", 4)):
+            if mode != args.mode:
+                r, _, _, _, _, sz = measure(mode, n_pool, max(50, args.steps // 4), 20, 0.05, True)
+                others[name] = {"MPix/s": round(r, 1), "jpeg_bytes_image0": sz, "input_pool_images": n_pool}
+        out["other_measurements"] = others
+
+    # ---- roofline of the fused colour+FDCT+quantise+zigzag kernel, live, on the library's stream ----
+    roofline, one_ms = forward_kernel_roofline(job, ctx, pool, W, H, lum, chrom, batch)
+    # HBM bytes and instruction counts per launch from the PMC counters, collected in separate rocprofv3 passes
+    # over this same command (tools/refresh_profiles.sh); valid for the workload they were taken on
+    pmc = pmc_profile("r02_k1_issue.json") if (batch == 1 and args.mode == 0) else None
+    roofline["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
+    roofline["bound"] = "valu"
+    roofline["bound_note"] = ("vector-instruction issue, not memory: the reference's operation order (every product and "
+                              "sum of the transform rounded on its own, no FMA) fixes most of the instruction count; "
+                              "`frac` is the 9 B/px of algorithmic traffic over the HBM peak all the same")
+    if pmc:
+        insts, waves = pmc["valu_insts_per_wave"], pmc["waves_per_launch"]
+        per_inst = one_ms * 1e6 * SIMDS / (insts * waves)
+        roofline["valu"] = {"insts_per_wave": insts, "waves_per_launch": waves, "simds": SIMDS,
+                            "launch_ns_per_wave_instruction_per_simd": round(per_inst, 3),
+                            "measured_issue_ns_full_rate": VALU_FULL_RATE_NS, "measured_issue_ns_half_rate": VALU_HALF_RATE_NS,
+                            "half_rate_share_of_insts": pmc.get("half_rate_share"),
+                            "issue_frac_single_launch": round(pmc["issue_ns_per_wave"] * waves / SIMDS / (one_ms * 1e6), 4),
+                            "shader_clock_mhz_under_load": pmc.get("shader_clock_mhz")}
+        if "marginal_us_per_step_of_work" in roofline:
+            roofline["valu"]["issue_frac_marginal"] = round(
+                pmc["issue_ns_per_wave"] * waves / SIMDS / (roofline["marginal_us_per_step_of_work"] * 1e3), 4)
+    # in the pipeline: phase durations of whole encodes (events between the kernels of one context)
+    ctx.set_profiling(True)
+    o = dict(out=torch.empty(capacity(args.mode), dtype=torch.uint8, device=job.dev), offsets=torch.zeros(batch, dtype=torch.int64, device=job.dev),
+             sizes=torch.zeros(batch, dtype=torch.int64, device=job.dev), status=torch.zeros(16, dtype=torch.int32, device=job.dev))
+    acc = [0.0, 0.0, 0.0]
+    reps = 40
+    for i in range(reps + 5):
+        ctx.encode_batch_async(pool.whole[(i % (len(pool) // batch)) * batch * 3 * W * H:][: batch * 3 * W * H], batch, W, H, lum, chrom,
+                               o["out"], o["offsets"], o["sizes"], o["status"])
+        ph = ctx.last_phase_ms()
+        if i >= 5:
+            acc = [a + p for a, p in zip(acc, ph)]
+    ctx.set_profiling(False)
+    roofline["pipeline_phase_us"] = {"forward_transform": round(acc[0] / reps * 1e3, 2), "bit_strings": round(acc[1] / reps * 1e3, 2),
+                                     "scans_pack_stuff": round(acc[2] / reps * 1e3, 2),
+                                     "note": "one context, events between its kernels, one encode at a time"}
+    out["roofline"] = roofline
+
+    cpu = None
+    if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_encode_baseline(po, imgs, QUALITY, max(1, args.cpu_images), CPU_THREADS)
+        # host to host: pageable caller memory in, file in caller memory out (PCIe both ways); never `value`
+        t0 = time.perf_counter()
+        n_h2h = 8
+        for i in range(n_h2h):
+            ctx.encode_host(imgs[i % len(imgs)], lum, chrom)
+        out["host_to_host"] = {"MPix/s": round(n_h2h * W * H / (time.perf_counter() - t0) / 1e6, 1),
+                               "note": "jea_encode_host: 24.9 MB of pageable host memory in over PCIe, file back out; one context"}
+    out["cpu_baseline"] = cpu
+    for c in ctxs:
+        c.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+FRAMES, FW, FH = 1024, 1920, 1080
+
+
+def rank_frames(job, po):
+    """This rank's share of the 1024 distinct frames (smooth pictures with their own noise; every 64th is noise)."""
+    import numpy as np
+
+    sharding = importlib.import_module("jpeg-encoder_amd.sharding")
+    mine = sharding.image_range(FRAMES if not job.args.frames else job.args.frames, job.world, job.rank)
+    with concurrent.futures.ThreadPoolExecutor(CPU_THREADS) as tp:
+        return np.stack(list(tp.map(lambda i: po.gen_image(FW, FH, 1 if i % 64 == 63 else 0, 1234 + i), mine))), mine
+
+
+def config_c3(job):
+    import numpy as np
+    import pyoracle as po
+
+    args, torch, binding = job.args, job.torch, job.binding
+    QUALITY = 90
+    ctx = job.pkg.Context(job.device_index)
+    lum, chrom = binding.quant_tables(QUALITY)
+    frames, mine = rank_frames(job, po)
+    n = len(mine)
+    pool = make_pool(ctx, frames)
+    sample = sorted(set([0, n // 2, n - 1]))
+    want = {i: po.encode(frames[i], QUALITY) for i in sample}
+    cap = n * (1 << 20) + (n // 64 + 1) * (4 << 20)
+    o = dict(out=torch.empty(cap, dtype=torch.uint8, device=job.dev), offsets=torch.zeros(n, dtype=torch.int64, device=job.dev),
+             sizes=torch.zeros(n, dtype=torch.int64, device=job.dev), status=torch.zeros(16, dtype=torch.int32, device=job.dev))
+
+    def step():
+        ctx.encode_batch_async(pool.whole, n, FW, FH, lum, chrom, o["out"], o["offsets"], o["sizes"], o["status"])
+
+    step()
+    ctx.synchronize()
+    assert int(o["status"][0].item()) == 0
+    offs, sizes = o["offsets"].cpu().numpy(), o["sizes"].cpu().numpy()
+    for i in sample:
+        if o["out"][int(offs[i]): int(offs[i] + sizes[i])].cpu().numpy().tobytes() != want[i]:
+            raise SystemExit("bench: GPU JPEG %d differs from the oracle's; refusing to report a number" % i)
+    seconds, regions = job.timed(step, ctx.synchronize)
+    value = job.sum_over_ranks(args.steps * n * FW * FH) / seconds / 1e6
+    roofline, _ = forward_kernel_roofline(job, ctx, [pool.whole], FW, FH, lum, chrom, n)
+    roofline["bound"] = "valu"
+    roofline["traffic"] = None
+    ctx.set_profiling(True)
+    step()
+    ph = ctx.last_phase_ms()
+    ctx.set_profiling(False)
+    roofline["pipeline_phase_us"] = {"forward_transform": round(ph[0] * 1e3, 1), "bit_strings": round(ph[1] * 1e3, 1),
+                                     "scans_pack_stuff": round(ph[2] * 1e3, 1)}
+    cpu = None
+    if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_encode_baseline(po, frames[:32], QUALITY, 32, CPU_THREADS)
+    out = {"metric": "encode MPix/s (q=90)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic RGB8 frames (seeds 1234+i; every 64th uniform noise), resident in HBM",
+           "config": {"workload": "batch of %d 1920x1080 frames at q=90, sharded by image, %d per rank, one encode call per step"
+                      % (job.sum_over_ranks(n), n), "width": FW, "height": FH, "quality": QUALITY,
+                      "byte_identical_to_oracle_sampled": len(sample), "sharding": "images by rank, no collective",
+                      **region_stats(regions)},
+           "roofline": roofline, "cpu_baseline": cpu}
+    ctx.close()
+    return out
+
+
+def config_c5(job):
+    import numpy as np
+    import pyoracle as po
+
+    args, torch, binding = job.args, job.torch, job.binding
+    QUALITY = 50
+    ctx = job.pkg.Context(job.device_index)
+    lum, chrom = binding.quant_tables(QUALITY)
+    frames, mine = rank_frames(job, po)
+    n = len(mine)
+    d_rgb = ctx.to_device(frames.reshape(-1))
+    d_jpeg, offs, sizes = ctx.encode_batch(d_rgb, n, FW, FH, lum, chrom, capacity=n * (1 << 19) + (n // 64 + 1) * (3 << 20))
+    del d_rgb
+    sample = sorted(set([0, n // 2, n - 1]))
+    host = d_jpeg.cpu().numpy()
+    files = {i: host[int(offs[i]): int(offs[i] + sizes[i])].tobytes() for i in sample}
+    d_out = ctx.empty(n * 3 * FW * FH, torch.uint8)
+    lib, handle = ctx.lib, ctx.handle
+    offs_c, sizes_c = np.ascontiguousarray(offs, np.uint64), np.ascontiguousarray(sizes, np.uint64)
+
+    def step():   # jea_decode_batch waits for the GPU itself (it reports the stream's errors)
+        ctx._check(lib.jea_decode_batch(handle, d_jpeg.data_ptr(), offs_c.ctypes.data, sizes_c.ctypes.data, n, FW, FH,
+                                        lum.ctypes.data, chrom.ctypes.data, d_out.data_ptr()))
+
+    step()
+    got = d_out.view(n, FH, FW, 3)
+    for i in sample:
+        if not np.array_equal(got[i].cpu().numpy(), po.decode(files[i], FW, FH, QUALITY)):
+            raise SystemExit("bench: GPU decode of file %d differs from the oracle's; refusing to report a number" % i)
+    seconds, regions = job.timed(step, ctx.synchronize)
+    value = job.sum_over_ranks(args.steps * n * FW * FH) / seconds / 1e6
+    ctx.set_profiling(True)
+    acc = [0.0] * 4
+    for _ in range(5):
+        step()
+        acc = [a + p for a, p in zip(acc, ctx.last_phase_ms())]
+    ctx.set_profiling(False)
+    ph = [a / 5 for a in acc]
+    stream_bytes = float(sizes.sum())
+    px = n * FW * FH
+    inv_bytes = INVERSE_BYTES_PER_PIXEL * px
+    roofline = {"kernel": "idct_dequant_kernel", "bound": "valu", "achieved": round(inv_bytes / (ph[3] * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(inv_bytes / (ph[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": None, "avg_launch_us": round(ph[3] * 1e3, 1), "algorithmic_bytes_per_launch": int(inv_bytes),
+                "bound_note": "6 B/px of coefficients read + 3 B/px written is the figure for the standard layout; inside "
+                              "jea_decode_batch the kernel reads block records and only the chunks that exist",
+                "other_kernels": {
+                    "decode_write_kernel(+scan)": {"us": round(ph[2] * 1e3, 1), "algorithmic_bytes": int(stream_bytes + 6 * px),
+                                                   "frac": round((stream_bytes + 6 * px) / (ph[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "note": "stream bytes read + 6 B/px of coefficients written (standard layout); "
+                                                           "bound by the latency of the serial walks, not by memory"},
+                    "decode_sync_kernel x2": {"us": round(ph[1] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes)},
+                    "unstuff kernels": {"us": round(ph[0] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes)}}}
+    cpu = None
+    if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        for i in sample:
+            po.decode(files[i], FW, FH, QUALITY)
+        single = len(sample) * FW * FH / (time.perf_counter() - t0) / 1e6
+        t0 = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(CPU_THREADS) as tp:
+            list(tp.map(lambda k: po.decode(files[sample[k % len(sample)]], FW, FH, QUALITY), range(2 * CPU_THREADS)))
+        allc = 2 * CPU_THREADS * FW * FH / (time.perf_counter() - t0) / 1e6
+        cpu = {"value": round(single, 2), "unit": "MPix/s", "cores": 1, "kind": "port",
+               "sample": "%d decodes of 1920x1080 q=50 files, one thread, oracle/jpeg_oracle.c" % len(sample),
+               "all_cores": {"value": round(allc, 2), "unit": "MPix/s", "cores": CPU_THREADS, "cpu_model": cpu_model()}}
+    out = {"metric": "decode MPix/s (q=50)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "JPEG files of synthetic frames (seeds 1234+i; every 64th uniform noise) encoded at q=50 by this library, resident in HBM",
+           "config": {"workload": "batched decode of %d 1920x1080 q=50 JPEG files, sharded by image, %d per rank, one decode call per step"
+                      % (job.sum_over_ranks(n), n), "width": FW, "height": FH, "quality": QUALITY,
+                      "jpeg_bytes_per_rank": int(stream_bytes), "bit_exact_with_oracle_sampled": len(sample),
+                      "sharding": "images by rank, no collective", **region_stats(regions)},
+           "roofline": roofline, "cpu_baseline": cpu}
+    ctx.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+def config_c4(job):
+    import numpy as np
+    import pyoracle as po
+
+    args, torch, binding = job.args, job.torch, job.binding
+    stripes = importlib.import_module("jpeg-encoder_amd.stripes")
+    W = H = args.c4_size
+    QUALITY = 75
+    ctx = job.pkg.Context(job.device_index)
+    lum, chrom = binding.quant_tables(QUALITY)
+    rows = stripes.stripe_rows(H, job.world)
+    if len(rows) != job.world:
+        raise SystemExit("bench: %d ranks but only %d MCU rows" % (job.world, len(rows)))
+    y0, y1 = rows[job.rank]
+    image = po.gen_image(W, H, 0, 1234)            # every rank generates the picture and keeps its stripe
+    d_rgb = ctx.to_device(image[y0:y1].reshape(-1))
+    del image
+    # the segment buffer is the caller's: smooth content stays far below 1.5 bytes per pixel (the worst case is 19)
+    d_segment = torch.empty(3 * W * (y1 - y0) // 2 + (1 << 20), dtype=torch.uint8, device=job.dev)
+    backend = stripes.HipBackend(ctx, d_rgb, W, y1 - y0, lum, chrom, capacity=d_segment.numel(), d_segment=d_segment)
+    if job.dist is not None:
+        gather = stripes.dist_all_gather(job.dist, job.comm_device)
+    else:
+        gather = lambda values: [list(values)]
+    result = {}
+
+    def step():
+        seg = stripes.encode_stripe(backend, job.rank, job.world, gather, W, H, on_device=True)
+        result["file"] = stripes.gather_segments_device(seg, job.dist, job.comm_device) if job.dist is not None else seg
+
+    step()
+    checked = None
+    if job.rank == 0:
+        golden = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_hashes.json")))["rows"]
+        row = [r for r in golden if (r["w"], r["h"], r["q"], r["mode"]) == (W, H, QUALITY, 0)]
+        jpeg = result["file"].cpu().numpy().tobytes()
+        if row:
+            if len(jpeg) != row[0]["jpeg_bytes"] or po.fnv(jpeg) != row[0]["jpeg_fnv"]:
+                raise SystemExit("bench: striped file differs from the recorded reference hash; refusing to report a number")
+            checked = "recorded reference hash %s" % row[0]["jpeg_fnv"]
+        else:
+            if jpeg != po.encode(po.gen_image(W, H, 0, 1234), QUALITY):
+                raise SystemExit("bench: striped file differs from the oracle's; refusing to report a number")
+            checked = "oracle, byte for byte"
+    # no time-based ramp here: a step contains collectives, so every rank must run the same number of steps
+    seconds, regions = job.timed(step, ctx.synchronize, ramp=0.0)
+    value = args.steps * W * H / seconds / 1e6
+    ctx.set_profiling(False)
+    mcus = binding.n_mcu(W, y1 - y0)
+    roofline, _ = forward_kernel_roofline(job, ctx, [d_rgb], W, y1 - y0, lum, chrom, 1)
+    roofline["bound"] = "valu"
+    roofline["traffic"] = None
+    cpu = None
+    if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+        sample = po.gen_image(W, min(H, 1024), 0, 1234)
+        t0 = time.perf_counter()
+        po.encode(sample, QUALITY)
+        cpu = {"value": round(sample.shape[0] * W / (time.perf_counter() - t0) / 1e6, 2), "unit": "MPix/s", "cores": 1,
+               "kind": "port", "sample": "one encode of the top %d rows of the image, one thread, oracle/jpeg_oracle.c "
+                                         "(one image: only the single-thread figure is meaningful)" % sample.shape[0]}
+    out = {"metric": "encode MPix/s (q=75)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic smooth RGB8 (seed 1234), each rank's stripe resident in HBM",
+           "config": {"workload": "single %dx%d image at q=75 as %d MCU-row stripe(s), one per rank; per step: transform, "
+                                  "all-gather of DC predictors, bit strings, all-gather of bit counts and head bits, pack and "
+                                  "stuff, gather of the segments on rank 0" % (W, H, job.world),
+                      "width": W, "height": H, "quality": QUALITY, "stripe_rows": y1 - y0, "file_checked_against": checked,
+                      "collectives": "2 all-gathers of a few bytes + 1 gather of the segments per step (%s)" % job.backend,
+                      **region_stats(regions)},
+           "roofline": roofline, "cpu_baseline": cpu}
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=1, help="images per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--batch", type=int, default=1, help="c2: images per step")
     ap.add_argument("--streams", type=int, default=3,
-                    help="contexts (HIP streams) the steps alternate over; independent images overlap")
+                    help="c2: contexts (HIP streams) the steps alternate over; independent images overlap")
+    ap.add_argument("--pool", type=int, default=16, help="c2: distinct input images the steps rotate over")
     ap.add_argument("--mode", type=int, default=0,
-                    help="0 smooth gradients + noise (the default workload), 1 uniform noise, 2 photo-like 1/f noise")
+                    help="c2: 0 smooth gradients + noise (the recorded workload), 1 uniform noise, 2 photo-like 1/f noise")
+    ap.add_argument("--frames", type=int, default=0, help="c3/c5: frames in the whole job (default 1024)")
+    ap.add_argument("--c4-size", type=int, default=16384, help="c4: width = height of the image")
     ap.add_argument("--ramp-seconds", type=float, default=0.1,
                     help="untimed steps before the warm-up, for the GPU clocks (0 for counter-collection runs)")
+    ap.add_argument("--quick", action="store_true", help="c2: only the headline measurement and the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=10, help="images of the CPU sample")
+    ap.add_argument("--cpu-images", type=int, default=10, help="c2: images of the single-thread CPU sample")
     args = ap.parse_args()
-
-    import numpy as np
-    import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    dist = None
-    n_devices = torch.cuda.device_count()
-    # One rank per GPU.  JEA_DIST_BACKEND=gloo rehearses the multi-process flow on a box with fewer
-    # GPUs than ranks (ranks then share devices); the measured runs use RCCL ("nccl").
-    backend = os.environ.get("JEA_DIST_BACKEND", "nccl")
-    if backend == "nccl" and local_rank >= n_devices:
-        raise SystemExit("bench: rank %d has no GPU of its own (%d visible)" % (local_rank, n_devices))
-    device_index = local_rank % max(1, n_devices)
-    if world > 1:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(device_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend)
-
-    pkg = importlib.import_module("jpeg-encoder_amd")
-    binding = pkg.binding
-    ctxs = [pkg.Context(device_index) for _ in range(max(1, args.streams))]
-    ctx = ctxs[0]
-    dev = ctx.tdev
-    lum, chrom = binding.quant_tables(QUALITY)
-
-    # synthetic input, resident in HBM before the timed region; every rank gets its own images
-    import pyoracle as po  # generator + checker only; nothing timed on the GPU side calls it
-
-    gen = (lambda seed: photo_like_image(W, H, seed)) if args.mode == 2 else (lambda seed: po.gen_image(W, H, args.mode, seed))
-    imgs = np.stack([gen(1234 + rank * args.batch + i) for i in range(args.batch)])
-    d_rgb = ctx.to_device(imgs.reshape(-1))
-    cap = args.batch * (3 * W * H // 2 + (1 << 20)) if args.mode == 0 else args.batch * binding.max_jpeg_bytes(W, H)
-    # every context has its own output and bookkeeping buffers; the input images are shared (read only)
-    outs = [dict(out=torch.empty(cap, dtype=torch.uint8, device=dev),
-                 offsets=torch.zeros(args.batch, dtype=torch.int64, device=dev),
-                 sizes=torch.zeros(args.batch, dtype=torch.int64, device=dev),
-                 status=torch.zeros(16, dtype=torch.int32, device=dev)) for _ in ctxs]
-    d_out, d_offsets, d_sizes, d_status = (outs[0][k] for k in ("out", "offsets", "sizes", "status"))
-    torch.cuda.synchronize(dev)
-    turn = [0]
-
-    def step():
-        i = turn[0] % len(ctxs)
-        turn[0] += 1
-        o = outs[i]
-        ctxs[i].encode_batch_async(d_rgb, args.batch, W, H, lum, chrom, o["out"], o["offsets"], o["sizes"], o["status"])
-
-    def sync_all():
-        for c in ctxs:
-            c.synchronize()
-
-    # parity gate before timing: the first image's file must equal the oracle's, byte for byte
-    for _ in ctxs:
-        step()
-    sync_all()
-    for o in outs:
-        assert int(o["status"][0].item()) == 0, "encode reported status %d" % int(o["status"][0].item())
-        assert torch.equal(o["out"][: int(o["sizes"][0].item())], d_out[: int(d_sizes[0].item())])
-    off0, size0 = int(d_offsets[0].item()), int(d_sizes[0].item())
-    gpu_file = d_out[off0: off0 + size0].cpu().numpy().tobytes()
-    parity = gpu_file == po.encode(imgs[0], QUALITY)
-    if not parity:
-        raise SystemExit("bench: GPU JPEG differs from the oracle's; refusing to report a number")
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        sync_all()
-        torch.cuda.synchronize(dev)
-
-    # The parity gate above left the GPU idle while the CPU encoded; its clocks take some milliseconds of
-    # load to come back up.  Untimed steps until 0.1 s has passed, then the W warm-up steps as asked.
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:
-        for _ in range(50):
-            step()
-        sync_all()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0   # this rank's time; the job's is the maximum over ranks (below)
-    barrier()
-    assert all(int(o["status"][0].item()) == 0 for o in outs)
-
-    # whole-job throughput: all ranks' pixels over the slowest rank's time
-    pixels_per_step = args.batch * W * H
-    sharding = importlib.import_module("jpeg-encoder_amd.sharding")
-    rate, elapsed = sharding.job_throughput(args.steps * pixels_per_step, elapsed, dist,
-                                            dev if backend == "nccl" else "cpu")
-    value = rate / 1e6
-
-    # ---- roofline of the fused colour+FDCT+quantise+zigzag kernel, live, on the library's stream ----
-    ext = torch.cuda.ExternalStream(ctx.stream_handle, device=dev)
-    # the variant the fused encode runs: chunk-planar coefficients, all-zero chunks not stored
-    d_coefs = torch.empty(args.batch * binding.n_mcu(W, H) * 192, dtype=torch.int16, device=dev)
-    d_masks = torch.empty(args.batch * binding.n_mcu(W, H) * 3, dtype=torch.uint8, device=dev)
-    reps = 50
-    with torch.cuda.stream(ext):
-        for _ in range(5):
-            ctx.fdct_quant_planar_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs, d_masks)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ctx.fdct_quant_planar_async(d_rgb, args.batch, W, H, lum, chrom, d_coefs, d_masks)
-        e1.record()
-    ctx.synchronize()
-    k1_ms = e0.elapsed_time(e1) / reps
-    k1_bytes = K1_BYTES_PER_PIXEL * pixels_per_step
-    achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
-    # The same kernel with four times the work per launch: the difference is the cost of one more
-    # step's worth of work once the launch's fixed latency (first and last workgroups running on a
-    # half-empty GPU) is paid -- what a stream of back-to-back images sees.
-    steady = None
-    if args.batch * W * H <= 64 << 20:
-        d_rgb4 = d_rgb.repeat(4)
-        d_coefs4 = torch.empty(4 * d_coefs.numel(), dtype=torch.int16, device=dev)
-        d_masks4 = torch.empty(4 * d_masks.numel(), dtype=torch.uint8, device=dev)
-        with torch.cuda.stream(ext):
-            for _ in range(3):
-                ctx.fdct_quant_planar_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4, d_masks4)
-            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e2.record()
-            for _ in range(20):
-                ctx.fdct_quant_planar_async(d_rgb4, 4 * args.batch, W, H, lum, chrom, d_coefs4, d_masks4)
-            e3.record()
-        ctx.synchronize()
-        k4_ms = e2.elapsed_time(e3) / 20
-        steady = max((k4_ms - k1_ms) / 3, 1e-6)
-        del d_rgb4, d_coefs4, d_masks4
-    # HBM bytes per launch from the PMC counters, collected in separate rocprofv3 passes on this same command
-    # and corrected for gfx950 as profiles/r01_pmc_traffic.json describes; only valid for the workload it was taken on
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.batch == 1 and args.mode == 0 and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["kernels"].get("fdct_quant_kernel", {}).get("hbm_bytes_per_launch")
-    roofline = {"kernel": "fdct_quant_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_us": round(k1_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(k1_bytes)}
-    if steady is not None:
-        roofline["marginal_us_per_step_of_work"] = round(steady * 1e3, 2)
-        roofline["marginal_frac"] = round(k1_bytes / (steady * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n = max(1, args.cpu_images)
-        t0 = time.perf_counter()
-        for i in range(n):
-            po.encode(imgs[i % args.batch], QUALITY)
-        dt = time.perf_counter() - t0
-        cpu_baseline = {"value": round(n * W * H / dt / 1e6, 2), "unit": "MPix/s", "cores": 1, "kind": "port",
-                        "sample": "%d x %dx%d q=%d encodes of the same synthetic image(s), single thread, "
-                                  "oracle/jpeg_oracle.c (byte-identical to the reference)" % (n, W, H, QUALITY)}
-
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        out = {
-            "metric": "encode MPix/s (q=75)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic %s RGB8 (seed 1234+), resident in HBM" % ("smooth", "noise", "photo-like")[args.mode],
-            "config": {"workload": "single 3840x2160 RGB image encode at q=75 per step" if args.batch == 1 else
-                       "%d x 3840x2160 RGB images encoded at q=75 per step" % args.batch,
-                       "images_per_step": args.batch, "width": W, "height": H, "quality": QUALITY,
-                       "jpeg_bytes_image0": size0, "byte_identical_to_oracle": parity,
-                       "streams": len(ctxs), "sharding": "images by rank, no collective",
-                       "untimed_ramp_seconds_before_warmup": args.ramp_seconds},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(out))
-    for c in ctxs:
-        c.close()
+    defaults = {"c2": (2000, 200), "c3": (10, 2), "c4": (10, 2), "c5": (10, 2)}[args.config]
+    if args.steps is None:
+        args.steps = defaults[0]
+    if args.warmup is None:
+        args.warmup = defaults[1]
+    job = Job(args)
+    out = {"c2": config_c2, "c3": config_c3, "c4": config_c4, "c5": config_c5}[args.config](job)
+    job.finish(out)
 
 
 if __name__ == "__main__":

@@ -346,8 +346,9 @@ class Context:
         self._check(self.lib.jea_stripe_bits(self.handle, dc.ctypes.data, ctypes.byref(bits), ctypes.byref(head)))
         return bits.value, head.value
 
-    def stripe_finish(self, bits_before, is_first, has_next, next_head, image_w, image_h, lum, chrom, capacity):
-        seg = self.empty(capacity, self.torch.uint8)
+    def stripe_finish(self, bits_before, is_first, has_next, next_head, image_w, image_h, lum, chrom, capacity, d_segment=None):
+        seg = d_segment if d_segment is not None else self.empty(capacity, self.torch.uint8)
+        capacity = min(capacity, seg.numel())
         n = ctypes.c_size_t(0)
         self._check(self.lib.jea_stripe_finish(self.handle, bits_before, int(is_first), int(has_next), next_head, image_w,
                                                image_h, lum.ctypes.data, chrom.ctypes.data, seg.data_ptr(), capacity,

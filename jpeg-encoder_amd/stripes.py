@@ -35,8 +35,9 @@ def stripe_rows(image_height, n_stripes):
 class HipBackend:
     """Stripe steps on one GPU through the C-ABI (jea_stripe_*)."""
 
-    def __init__(self, ctx, d_rgb_stripe, width, stripe_height, lum, chrom):
+    def __init__(self, ctx, d_rgb_stripe, width, stripe_height, lum, chrom, capacity=None, d_segment=None):
         self.ctx, self.d_rgb, self.w, self.h, self.lum, self.chrom = ctx, d_rgb_stripe, width, stripe_height, lum, chrom
+        self.capacity, self.d_segment = capacity, d_segment   # optional: segment size bound, caller's output buffer
 
     def transform(self):
         return self.ctx.stripe_transform(self.d_rgb, self.w, self.h, self.lum, self.chrom)
@@ -44,15 +45,18 @@ class HipBackend:
     def bits(self, prev_dc):
         return self.ctx.stripe_bits(prev_dc)
 
-    def finish(self, bits_before, is_first, has_next, next_head, image_w, image_h):
+    def finish(self, bits_before, is_first, has_next, next_head, image_w, image_h, on_device=False):
+        """The stripe's segment of the file: bytes, or (on_device) a uint8 tensor on the GPU."""
         n_mcu = ((self.w + 7) // 8) * ((self.h + 7) // 8)
-        capacity = 607 + 2 * ((n_mcu * 3 * 1660 + 7) // 8) + 16
+        # The worst case (every block at 1660 bits, every byte stuffed) is 19 bytes per pixel; a caller that
+        # knows its pictures may bound the segment more tightly with `capacity`.
+        capacity = self.capacity or 607 + 2 * ((n_mcu * 3 * 1660 + 7) // 8) + 16
         seg = self.ctx.stripe_finish(bits_before, is_first, has_next, next_head, image_w, image_h, self.lum,
-                                     self.chrom, capacity)
-        return bytes(seg.cpu().numpy().tobytes())
+                                     self.chrom, capacity, self.d_segment)
+        return seg if on_device else bytes(seg.cpu().numpy().tobytes())
 
 
-def encode_stripe(backend, rank, world, all_gather, image_w, image_h):
+def encode_stripe(backend, rank, world, all_gather, image_w, image_h, on_device=False):
     """What one rank runs.  all_gather(list_of_ints) -> list over ranks of such lists.  Returns the segment."""
     last_dc = backend.transform()
     dcs = all_gather(list(last_dc))
@@ -62,6 +66,8 @@ def encode_stripe(backend, rank, world, all_gather, image_w, image_h):
     bits_before = sum(f[0] for f in facts[:rank])
     has_next = rank + 1 < world
     next_head = facts[rank + 1][1] if has_next else 0
+    if on_device:
+        return backend.finish(bits_before, rank == 0, has_next, next_head, image_w, image_h, on_device=True)
     return backend.finish(bits_before, rank == 0, has_next, next_head, image_w, image_h)
 
 
@@ -105,3 +111,20 @@ def gather_segments(segment, dist, device="cpu", dst=0):
     if rank != dst:
         return None
     return b"".join(bytes(parts[r][: sizes[r][0]].cpu().numpy().tobytes()) for r in range(world))
+
+
+def gather_segments_device(segment, dist, device, dst=0):
+    """gather_segments for segments that are uint8 tensors on the GPU: rank `dst` receives the file as one
+    tensor on `device` (the GPU with RCCL; "cpu" with gloo), other ranks get None."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = dist_all_gather(dist, device)([int(segment.numel())])
+    longest = max(s[0] for s in sizes)
+    mine = torch.zeros(longest, dtype=torch.uint8, device=device)
+    mine[: segment.numel()] = segment.to(device)
+    parts = [torch.zeros_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, parts, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][: sizes[r][0]] for r in range(world)])

@@ -1,20 +1,37 @@
 #!/bin/bash
-# Regenerates what profiles/ holds, on the GPU box: bench line, kernel stats with three contexts and with one,
-# the bench lines measured under the profiler, HBM traffic from two counter passes, decode kernel stats.
-# Results land in gpurun_out/profiles_new/.
+# Regenerates what profiles/ holds for this round, on the GPU box.  Results land in gpurun_out/profiles_new/.
+#   bench lines of all configurations, kernel durations (rocprofv3 --kernel-trace --stats) of the headline command with
+#   three contexts and with one, the forward kernel's issue counters and HBM traffic (separate --pmc passes), decode kernels.
 set -o pipefail
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/profiles_new"; mkdir -p "$O"
+P=r02
 cd "$R" || exit 1
-timeout -k 10 200 python bench.py > "$O/r01_bench_single4k.json" || exit 1
+timeout -k 10 300 python bench.py > "$O/${P}_bench_c2.json" 2> "$O/c2.err" || { tail -5 "$O/c2.err"; exit 1; }
+for c in c3 c4 c5; do
+  timeout -k 10 400 python bench.py --config $c > "$O/${P}_bench_$c.json" 2> "$O/$c.err" || { tail -5 "$O/$c.err"; exit 1; }
+done
+echo benches done
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/k3" -- python3 "$R/bench.py" --no-cpu-baseline > "$O/r01_bench_single4k_under_rocprof.json" 2> "$O/k3.err" || exit 1
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/k1" -- python3 "$R/bench.py" --no-cpu-baseline --streams 1 > "$O/r01_bench_single4k_1stream_under_rocprof.json" 2> "$O/k1.err" || exit 1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pf" -- python3 "$R/bench.py" --steps 20 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --streams 1 > "$O/pf.log" 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pw" -- python3 "$R/bench.py" --steps 20 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --streams 1 > "$O/pw.log" 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kd" -- python3 "$R/tools/time_decode.py" 1920 1080 50 0 1024 > "$O/kd.log" 2>&1 || exit 1
-cp "$O"/k3/*/*kernel_stats.csv "$O/r01_bench_single4k_kernel_stats.csv"
-cp "$O"/k1/*/*kernel_stats.csv "$O/r01_bench_single4k_1stream_kernel_stats.csv"
-cp "$O"/kd/*/*kernel_stats.csv "$O/r01_decode_1024x1080p_q50_kernel_stats.csv"
-python3 "$R/tools/pmc_summary.py" "$O/pf" "$O/pw" "single 3840x2160 q=75 smooth" > "$O/r01_pmc_traffic.json"
-rm -rf "$O"/k3 "$O"/k1 "$O"/kd "$O"/pf "$O"/pw
+Q="--quick --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/k3" -- python3 "$R/bench.py" $Q > "$O/${P}_bench_c2_3streams_under_rocprof.json" 2> "$O/k3.err" || { tail -5 "$O/k3.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/k1" -- python3 "$R/bench.py" $Q --streams 1 > "$O/${P}_bench_c2_1stream_under_rocprof.json" 2> "$O/k1.err" || { tail -5 "$O/k1.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/k5" -- python3 "$R/bench.py" --config c5 --no-cpu-baseline > "$O/${P}_bench_c5_under_rocprof.json" 2> "$O/k5.err" || { tail -5 "$O/k5.err"; exit 1; }
+echo traces done
+B="$Q --steps 20 --warmup 2 --ramp-seconds 0 --streams 1"
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
+timeout -s KILL 150 rocprofv3 --pmc $SQ --output-format csv -d "$O/pa" -- python3 "$R/bench.py" $B > "$O/pa.log" 2>&1 || { tail -5 "$O/pa.log"; exit 1; }
+timeout -s KILL 150 rocprofv3 --pmc $SQ --output-format csv -d "$O/pb" -- python3 "$R/bench.py" $B --batch 8 --pool 8 > "$O/pb.log" 2>&1 || { tail -5 "$O/pb.log"; exit 1; }
+timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pf" -- python3 "$R/bench.py" $B > "$O/pf.log" 2>&1 || { tail -5 "$O/pf.log"; exit 1; }
+timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pw" -- python3 "$R/bench.py" $B > "$O/pw.log" 2>&1 || { tail -5 "$O/pw.log"; exit 1; }
+echo counters done
+cd "$R"
+cp "$O"/k3/*/*kernel_stats.csv "$O/${P}_bench_c2_3streams_kernel_stats.csv"
+cp "$O"/k1/*/*kernel_stats.csv "$O/${P}_bench_c2_1stream_kernel_stats.csv"
+cp "$O"/k5/*/*kernel_stats.csv "$O/${P}_bench_c5_kernel_stats.csv"
+python3 tools/kernel_trace_summary.py "python3 bench.py $Q --streams 1" "$O/k1" > "$O/${P}_bench_c2_1stream_kernels_by_grid.json"
+python3 tools/kernel_trace_summary.py "python3 bench.py $Q" "$O/k3" > "$O/${P}_bench_c2_3streams_kernels_by_grid.json"
+python3 tools/kernel_trace_summary.py "python3 bench.py --config c5 --no-cpu-baseline" "$O/k5" > "$O/${P}_bench_c5_kernels_by_grid.json"
+python3 tools/k1_issue_summary.py "$O/pa" "$O/pb" "$O/pf" "$O/pw" > "$O/${P}_k1_issue.json" || exit 1
+python3 tools/pmc_summary.py "$O/pf" "$O/pw" "single 3840x2160 q=75 smooth" > "$O/${P}_pmc_traffic.json"
+rm -rf "$O"/k3 "$O"/k1 "$O"/k5 "$O"/pa "$O"/pb "$O"/pf "$O"/pw
 ls -la "$O"
