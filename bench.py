@@ -202,14 +202,20 @@ def cpu_encode_baseline(po, images, quality, n_single, threads):
                           "sample": "%d encodes, one image per thread on %d threads" % (n_all, threads)}}
 
 
-def forward_kernel_roofline(job, ctx, d_rgb_pool, w, h, lum, chrom, images_per_launch=1):
-    """Forward kernel alone, back to back on the library's stream, timed with HIP events on that stream."""
+def forward_kernel_roofline(job, ctx, groups, whole, w, h, lum, chrom, images_per_launch=1, marginal_images=8):
+    """Forward kernel alone, back to back on the library's stream, timed with HIP events on that stream.
+    `groups`: device tensors of `images_per_launch` images each, launched in rotation; `whole`: one tensor
+    that holds at least `marginal_images` images, or None."""
     torch, binding = job.torch, job.binding
     ext = torch.cuda.ExternalStream(ctx.stream_handle, device=job.dev)
     n = images_per_launch
     mcus = binding.n_mcu(w, h)
-    d_coefs = torch.empty(8 * n * mcus * 192, dtype=torch.int16, device=job.dev)
-    d_masks = torch.empty(8 * n * mcus * 3, dtype=torch.uint8, device=job.dev)
+    d_rgb_pool = list(groups)
+    for g in d_rgb_pool:
+        assert g.numel() >= n * 3 * w * h
+    many = marginal_images if (whole is not None and whole.numel() >= marginal_images * 3 * w * h and marginal_images > n) else 0
+    d_coefs = torch.empty(max(n, many) * mcus * 192, dtype=torch.int16, device=job.dev)
+    d_masks = torch.empty(max(n, many) * mcus * 3, dtype=torch.uint8, device=job.dev)
 
     def launches(images, reps):
         with torch.cuda.stream(ext):
@@ -228,24 +234,24 @@ def forward_kernel_roofline(job, ctx, d_rgb_pool, w, h, lum, chrom, images_per_l
     roof = {"kernel": "fdct_quant_kernel", "achieved": round(k_bytes / (one * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(k_bytes / (one * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_us": round(one * 1e3, 2), "algorithmic_bytes_per_launch": int(k_bytes)}
-    # The same kernel with eight times the work per launch (the pool's images side by side, when the pool is one
-    # buffer of at least that many): the difference is the cost of one more step's worth of work once the
-    # launch's fixed latency (first and last workgroups running on a half-empty GPU) is paid.
-    whole = getattr(d_rgb_pool, "whole", None)
-    if whole is not None and whole.numel() >= 8 * n * 3 * w * h:
+    # The same kernel with several times the work per launch (images of the pool side by side): the difference is
+    # the cost of one more image once the launch's fixed latency (first and last workgroups running on a
+    # half-empty GPU) is paid.
+    if many:
         with torch.cuda.stream(ext):
             e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(2):
-                ctx.fdct_quant_planar_async(whole, 8 * n, w, h, lum, chrom, d_coefs, d_masks)
+                ctx.fdct_quant_planar_async(whole, many, w, h, lum, chrom, d_coefs, d_masks)
             e2.record()
             for _ in range(12):
-                ctx.fdct_quant_planar_async(whole, 8 * n, w, h, lum, chrom, d_coefs, d_masks)
+                ctx.fdct_quant_planar_async(whole, many, w, h, lum, chrom, d_coefs, d_masks)
             e3.record()
         ctx.synchronize()
-        eight = e2.elapsed_time(e3) / 12
-        steady = max((eight - one) / 7, 1e-6)
-        roof["marginal_us_per_step_of_work"] = round(steady * 1e3, 2)
-        roof["marginal_frac"] = round(k_bytes / (steady * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        big = e2.elapsed_time(e3) / 12
+        steady = max((big - one) / (many - n), 1e-6)      # per image
+        roof["marginal_launch_images"] = many
+        roof["marginal_us_per_step_of_work"] = round(steady * n * 1e3, 2)
+        roof["marginal_frac"] = round(K1_BYTES_PER_PIXEL * w * h / (steady * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return roof, one
 
 
@@ -326,17 +332,17 @@ def config_c2(job):
         seconds, regions = job.timed(step, sync_all, steps, warmup, ramp)
         assert all(int(o["status"][0].item()) == 0 for o in outs)
         rate = job.sum_over_ranks(steps * batch * W * H) / seconds / 1e6
-        return rate, seconds, regions, pool, imgs, size0
+        return rate, seconds, regions, pool, imgs, size0, groups
 
-    value, seconds, regions, pool, imgs, size0 = measure(args.mode, args.pool, args.steps, args.warmup, args.ramp_seconds, True)
+    value, seconds, regions, pool, imgs, size0, groups = measure(args.mode, args.pool, args.steps, args.warmup, args.ramp_seconds, True)
 
     out = {
         "metric": "encode MPix/s (q=75)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic %s RGB8 (seeds 1234+), %d distinct images per rank resident in HBM (%d MB, more than the "
-                "256 MB Infinity Cache), read in rotation" % (("smooth", "noise", "photo-like")[args.mode], len(pool),
-                                                              len(pool) * 3 * W * H >> 20),
+        "data": "synthetic %s RGB8 (seeds 1234+), %d distinct images per rank resident in HBM (%d MB; the Infinity Cache "
+                "holds 256 MB), read in rotation" % (("smooth", "noise", "photo-like")[args.mode], len(pool),
+                                                     len(pool) * 3 * W * H >> 20),
         "config": {"workload": "single 3840x2160 RGB image encode at q=75 per step" if batch == 1 else
                    "%d x 3840x2160 RGB images encoded at q=75 per step" % batch,
                    "images_per_step": batch, "width": W, "height": H, "quality": QUALITY,
@@ -349,20 +355,21 @@ def config_c2(job):
         # ---- the same measurement in other settings, each labelled; none of them is `value` ----
         others = {}
         lat_ctxs, ctxs[:] = ctxs[:], ctxs[:1]                     # one context: images strictly one after the other
-        r, s, _, _, _, _ = measure(args.mode, args.pool, max(50, args.steps // 4), 20, 0.05, False)
+        r, s = measure(args.mode, args.pool, max(50, args.steps // 4), 20, 0.05, False)[:2]
         others["one_stream_latency"] = {"MPix/s": round(r, 1), "us_per_image": round(s / max(50, args.steps // 4) * 1e6 / batch, 2),
                                         "note": "one context, every image waits for the one before"}
         ctxs[:] = lat_ctxs
-        r, _, _, _, _, _ = measure(args.mode, batch, max(50, args.steps // 4), 20, 0.05, False)
+        r = measure(args.mode, batch, max(50, args.steps // 4), 20, 0.05, False)[0]
         others["input_cached"] = {"MPix/s": round(r, 1), "note": "every step encodes the same image (it stays in the Infinity Cache)"}
         for mode, name, n_pool in ((2, "photo_like", 2), (1, "noise", 4)):
             if mode != args.mode:
-                r, _, _, _, _, sz = measure(mode, n_pool, max(50, args.steps // 4), 20, 0.05, True)
+                res = measure(mode, n_pool, max(50, args.steps // 4), 20, 0.05, True)
+                r, sz = res[0], res[5]
                 others[name] = {"MPix/s": round(r, 1), "jpeg_bytes_image0": sz, "input_pool_images": n_pool}
         out["other_measurements"] = others
 
     # ---- roofline of the fused colour+FDCT+quantise+zigzag kernel, live, on the library's stream ----
-    roofline, one_ms = forward_kernel_roofline(job, ctx, pool, W, H, lum, chrom, batch)
+    roofline, one_ms = forward_kernel_roofline(job, ctx, groups, pool.whole, W, H, lum, chrom, batch, args.marginal_images)
     # HBM bytes and instruction counts per launch from the PMC counters, collected in separate rocprofv3 passes
     # over this same command (tools/refresh_profiles.sh); valid for the workload they were taken on
     pmc = pmc_profile("r02_k1_issue.json") if (batch == 1 and args.mode == 0) else None
@@ -390,8 +397,7 @@ def config_c2(job):
     acc = [0.0, 0.0, 0.0]
     reps = 40
     for i in range(reps + 5):
-        ctx.encode_batch_async(pool.whole[(i % (len(pool) // batch)) * batch * 3 * W * H:][: batch * 3 * W * H], batch, W, H, lum, chrom,
-                               o["out"], o["offsets"], o["sizes"], o["status"])
+        ctx.encode_batch_async(groups[i % len(groups)], batch, W, H, lum, chrom, o["out"], o["offsets"], o["sizes"], o["status"])
         ph = ctx.last_phase_ms()
         if i >= 5:
             acc = [a + p for a, p in zip(acc, ph)]
@@ -460,7 +466,7 @@ def config_c3(job):
             raise SystemExit("bench: GPU JPEG %d differs from the oracle's; refusing to report a number" % i)
     seconds, regions = job.timed(step, ctx.synchronize)
     value = job.sum_over_ranks(args.steps * n * FW * FH) / seconds / 1e6
-    roofline, _ = forward_kernel_roofline(job, ctx, [pool.whole], FW, FH, lum, chrom, n)
+    roofline, _ = forward_kernel_roofline(job, ctx, [pool.whole], None, FW, FH, lum, chrom, n)
     roofline["bound"] = "valu"
     roofline["traffic"] = None
     ctx.set_profiling(True)
@@ -614,7 +620,7 @@ def config_c4(job):
     value = args.steps * W * H / seconds / 1e6
     ctx.set_profiling(False)
     mcus = binding.n_mcu(W, y1 - y0)
-    roofline, _ = forward_kernel_roofline(job, ctx, [d_rgb], W, y1 - y0, lum, chrom, 1)
+    roofline, _ = forward_kernel_roofline(job, ctx, [d_rgb], None, W, y1 - y0, lum, chrom, 1)
     roofline["bound"] = "valu"
     roofline["traffic"] = None
     cpu = None
@@ -650,6 +656,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="c2: contexts (HIP streams) the steps alternate over; independent images overlap")
     ap.add_argument("--pool", type=int, default=16, help="c2: distinct input images the steps rotate over")
+    ap.add_argument("--marginal-images", type=int, default=8,
+                    help="c2: images of the large forward-kernel launch that gives the marginal cost per image (at most --pool)")
     ap.add_argument("--mode", type=int, default=0,
                     help="c2: 0 smooth gradients + noise (the recorded workload), 1 uniform noise, 2 photo-like 1/f noise")
     ap.add_argument("--frames", type=int, default=0, help="c3/c5: frames in the whole job (default 1024)")

@@ -184,6 +184,13 @@ class Context:
         except Exception:
             pass
 
+    @staticmethod
+    def _need(tensor, n_elements, what):
+        """The C ABI takes raw pointers and trusts the sizes it is told; a tensor that is too short would make
+        the kernels read or write past its end, so the binding refuses it here."""
+        if tensor.numel() < int(n_elements):
+            raise ValueError("%s holds %d elements, the call needs %d" % (what, tensor.numel(), int(n_elements)))
+
     def _check(self, rc):
         if rc:
             raise JeaError(rc, self.lib.jea_last_error(self.handle).decode())
@@ -225,6 +232,7 @@ class Context:
 
     # ---- stages ----
     def fdct_quant(self, d_rgb, n_images, w, h, lum, chrom):
+        self._need(d_rgb, n_images * 3 * w * h, "d_rgb")
         coefs = self.empty(n_images * n_mcu(w, h) * 192, self.torch.int16)
         self.torch.cuda.synchronize(self.tdev)
         self._check(self.lib.jea_fdct_quant(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
@@ -232,15 +240,21 @@ class Context:
         return coefs
 
     def fdct_quant_async(self, d_rgb, n_images, w, h, lum, chrom, d_coefs):
+        self._need(d_rgb, n_images * 3 * w * h, "d_rgb")
+        self._need(d_coefs, n_images * n_mcu(w, h) * 192, "d_coefs")
         self._check(self.lib.jea_fdct_quant_async(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
                                                   chrom.ctypes.data, d_coefs.data_ptr()))
 
     def fdct_quant_planar_async(self, d_rgb, n_images, w, h, lum, chrom, d_coefs_planar, d_masks):
+        self._need(d_rgb, n_images * 3 * w * h, "d_rgb")
+        self._need(d_coefs_planar, n_images * n_mcu(w, h) * 192, "d_coefs_planar")
+        self._need(d_masks, n_images * n_mcu(w, h) * 3, "d_masks")
         self._check(self.lib.jea_fdct_quant_planar_async(self.handle, d_rgb.data_ptr(), n_images, w, h,
                                                          lum.ctypes.data, chrom.ctypes.data, d_coefs_planar.data_ptr(),
                                                          d_masks.data_ptr()))
 
     def idct_dequant(self, d_coefs, n_images, w, h, lum, chrom):
+        self._need(d_coefs, n_images * n_mcu(w, h) * 192, "d_coefs")
         rgb = self.empty(n_images * 3 * w * h, self.torch.uint8)
         self.torch.cuda.synchronize(self.tdev)
         self._check(self.lib.jea_idct_dequant(self.handle, d_coefs.data_ptr(), n_images, w, h, lum.ctypes.data,
@@ -248,12 +262,14 @@ class Context:
         return rgb
 
     def block_bit_lengths(self, d_coefs, n_images, mcus):
+        self._need(d_coefs, n_images * mcus * 192, "d_coefs")
         out = self.empty(n_images * mcus * 3, self.torch.int16)
         self.torch.cuda.synchronize(self.tdev)
         self._check(self.lib.jea_block_bit_lengths(self.handle, d_coefs.data_ptr(), n_images, mcus, out.data_ptr()))
         return out
 
     def entropy_encode(self, d_coefs, n_images, mcus, capacity):
+        self._need(d_coefs, n_images * mcus * 192, "d_coefs")
         out = self.empty(capacity, self.torch.uint8)
         offsets, sizes = np.zeros(n_images, np.uint64), np.zeros(n_images, np.uint64)
         self.torch.cuda.synchronize(self.tdev)
@@ -334,6 +350,7 @@ class Context:
 
     # ---- stripes of one image ----
     def stripe_transform(self, d_rgb_stripe, w, stripe_h, lum, chrom):
+        self._need(d_rgb_stripe, 3 * w * stripe_h, "d_rgb_stripe")
         dc = np.zeros(3, np.int16)
         self.torch.cuda.synchronize(self.tdev)
         self._check(self.lib.jea_stripe_transform(self.handle, d_rgb_stripe.data_ptr(), w, stripe_h, lum.ctypes.data,
@@ -361,6 +378,8 @@ class Context:
             capacity = n_images * max_jpeg_bytes(w, h)
         if d_out is None:
             d_out = self.empty(capacity, self.torch.uint8)
+        self._need(d_rgb, n_images * 3 * w * h, "d_rgb")
+        self._need(d_out, capacity, "d_out")
         offsets, sizes = np.zeros(n_images, np.uint64), np.zeros(n_images, np.uint64)
         self.torch.cuda.synchronize(self.tdev)
         self._check(self.lib.jea_encode_batch(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
@@ -368,13 +387,21 @@ class Context:
                                               sizes.ctypes.data))
         return d_out, offsets, sizes
 
+    def _need_encode_buffers(self, d_rgb, n_images, w, h, d_offsets, d_sizes, d_status):
+        self._need(d_rgb, n_images * 3 * w * h, "d_rgb")
+        self._need(d_offsets, n_images, "d_offsets")
+        self._need(d_sizes, n_images, "d_sizes")
+        self._need(d_status, 1, "d_status")
+
     def encode_batch_async(self, d_rgb, n_images, w, h, lum, chrom, d_out, d_offsets, d_sizes, d_status):
+        self._need_encode_buffers(d_rgb, n_images, w, h, d_offsets, d_sizes, d_status)
         self._check(self.lib.jea_encode_batch_async(self.handle, d_rgb.data_ptr(), n_images, w, h, lum.ctypes.data,
                                                     chrom.ctypes.data, d_out.data_ptr(), d_out.numel(),
                                                     d_offsets.data_ptr(), d_sizes.data_ptr(), d_status.data_ptr()))
 
     def encode_batch_static_async(self, d_rgb, n_images, w, h, lum, chrom, d_out, d_offsets, d_sizes, d_status):
         """jea_encode_batch_async on the library's built-in scratch: no allocation inside the call."""
+        self._need_encode_buffers(d_rgb, n_images, w, h, d_offsets, d_sizes, d_status)
         self._check(self.lib.jea_encode_batch_static_async(self.handle, d_rgb.data_ptr(), n_images, w, h,
                                                            lum.ctypes.data, chrom.ctypes.data, d_out.data_ptr(),
                                                            d_out.numel(), d_offsets.data_ptr(), d_sizes.data_ptr(),
@@ -396,6 +423,8 @@ class Context:
         offsets = np.ascontiguousarray(offsets, np.uint64)
         sizes = np.ascontiguousarray(sizes, np.uint64)
         rgb = self.empty(n * 3 * w * h, self.torch.uint8)
+        if n:
+            self._need(d_jpeg, int((offsets + sizes).max()), "d_jpeg")
         self.torch.cuda.synchronize(self.tdev)
         self._check(self.lib.jea_decode_batch(self.handle, d_jpeg.data_ptr(), offsets.ctypes.data, sizes.ctypes.data,
                                               n, w, h, lum.ctypes.data, chrom.ctypes.data, rgb.data_ptr()))

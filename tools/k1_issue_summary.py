@@ -96,7 +96,7 @@ def main():
     issue_ns = insts * ((1 - share) * FULL_NS + share * HALF_NS)
     out = {
         "_how": "rocprofv3 --pmc passes over `python3 bench.py --quick --steps 20 --warmup 2 --ramp-seconds 0 --no-cpu-baseline "
-                "--streams 1` (single-image launches, grid 388800) and the same with --batch 8 (64 images per launch in the "
+                "--streams 1` (single-image launches, grid 388800) and the same with --pool 64 --marginal-images 64 (64 images per launch in the "
                 "roofline section); SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count in units of four cycles; "
                 "GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE doubled for gfx950 (a 128-byte request counts as 64), "
                 "both in KB; instruction classes from the ISA listing (tools/k1_issue_summary.py), issue costs from tools/valu_rates.hip",

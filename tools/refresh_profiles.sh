@@ -20,7 +20,7 @@ echo traces done
 B="$Q --steps 20 --warmup 2 --ramp-seconds 0 --streams 1"
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 timeout -s KILL 150 rocprofv3 --pmc $SQ --output-format csv -d "$O/pa" -- python3 "$R/bench.py" $B > "$O/pa.log" 2>&1 || { tail -5 "$O/pa.log"; exit 1; }
-timeout -s KILL 150 rocprofv3 --pmc $SQ --output-format csv -d "$O/pb" -- python3 "$R/bench.py" $B --batch 8 --pool 8 > "$O/pb.log" 2>&1 || { tail -5 "$O/pb.log"; exit 1; }
+timeout -s KILL 150 rocprofv3 --pmc $SQ --output-format csv -d "$O/pb" -- python3 "$R/bench.py" $B --pool 64 --marginal-images 64 > "$O/pb.log" 2>&1 || { tail -5 "$O/pb.log"; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pf" -- python3 "$R/bench.py" $B > "$O/pf.log" 2>&1 || { tail -5 "$O/pf.log"; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pw" -- python3 "$R/bench.py" $B > "$O/pw.log" 2>&1 || { tail -5 "$O/pw.log"; exit 1; }
 echo counters done
