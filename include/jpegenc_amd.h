@@ -269,6 +269,12 @@ int jea_entropy_encode(jea_ctx* ctx, const int16_t* d_coefs, size_t n_images, si
 int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_offsets, const uint64_t* h_sizes,
                        size_t n_images, size_t mcus_per_image, int16_t* d_coefs);
 
+/* BitStream::removeStuffedBytes (bit_stream.cpp:136-147) on its own: d_scan[0 .. len) is scan data followed by
+ * the two bytes of the EOI marker; the 0x00 after a 0xFF that lies before those two bytes is dropped --
+ * with the reference's way of walking: the byte after a 0xFF is never itself the 0xFF of a pair, so of a run
+ * of 0xFF bytes every second one counts.  d_out (len bytes of room) receives the *out_len remaining bytes. */
+int jea_remove_stuffing(jea_ctx* ctx, const uint8_t* d_scan, size_t len, uint8_t* d_out, size_t* out_len);
+
 /* De-zigzag + dequantise + separable 8x8 inverse DCT + level unshift +
  * YCbCr->RGB + cropped store.  Replaces entropy_encoder.cpp:79-92,
  * quantiser.cpp:72-85, discrete_cosine_transform.cpp:8-11,21-27,90-156,
@@ -318,6 +324,20 @@ int jea_huffman_encode_blocks(jea_ctx* ctx, const int16_t* h_zigzag, const int16
 int jea_stream_upload(jea_ctx* ctx, const uint8_t* h_stream, size_t len);
 int jea_huffman_decode_block(jea_ctx* ctx, uint64_t start_bit, int is_luminance, int16_t* last_dc,
                              int16_t h_zigzag[64], uint64_t* end_bit);
+
+/* HuffmanEncoder::applyFinalEncoding / removeFinalEncoding (entropy_encoder.cpp:696-712, 715-866): the
+ * final-encoding step on the run-length form of one block-channel, the level at which the reference lets a
+ * subclass of EntropyEncoder replace the coder (entropy_encoder.hpp:50-51).
+ * Encode: the DC difference and then every (run, value) entry as given; (0, 0) is the end-of-block code,
+ * (15, 0) the zero-run code, another entry with value 0 fails with the reference's "Invalid runtime encoding
+ * encountered." (JEA_ERR_RANGE), as do entries the tables have no code for.  h_bits needs
+ * (22 + 26 * n_entries + 31) / 32 words; bits are MSB first in each word, zero padded.
+ * Decode: from the stream given to jea_stream_upload, starting at start_bit; at most 64 entries. */
+int jea_huffman_encode_rle(jea_ctx* ctx, int16_t dc_difference, const uint16_t* h_runs, const int16_t* h_values,
+                           size_t n_entries, int is_luminance, uint32_t* length_bits, uint32_t* h_bits,
+                           size_t bits_capacity_words);
+int jea_huffman_decode_rle(jea_ctx* ctx, uint64_t start_bit, int is_luminance, int16_t* dc_difference,
+                           uint16_t h_runs[64], int16_t h_values[64], size_t* n_entries, uint64_t* end_bit);
 
 /* ---- device memory helpers for callers without a HIP binding ---------- */
 int jea_malloc(jea_ctx* ctx, size_t bytes, void** d_ptr);

@@ -19,11 +19,11 @@ EXPORTS = [
     "jea_encode_batch_static_async", "jea_static_scratch_needed",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
     "jea_decode_batch", "jea_decode_host",
-    "jea_fdct_quant", "jea_fdct_quant_async", "jea_fdct_quant_planar_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_idct_dequant",
+    "jea_fdct_quant", "jea_fdct_quant_async", "jea_fdct_quant_planar_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_remove_stuffing", "jea_idct_dequant",
     "jea_rgb_to_ycbcr", "jea_ycbcr_to_rgb",
     "jea_rgb_to_ycbcr_host", "jea_ycbcr_to_rgb_host", "jea_dct_forward_blocks", "jea_dct_inverse_blocks",
     "jea_quantise_blocks", "jea_dequantise_blocks", "jea_huffman_encode_blocks", "jea_stream_upload",
-    "jea_huffman_decode_block",
+    "jea_huffman_decode_block", "jea_huffman_encode_rle", "jea_huffman_decode_rle",
     "jea_malloc", "jea_free", "jea_memcpy_h2d", "jea_memcpy_d2h",
 ]
 
@@ -87,6 +87,7 @@ def load_library():
     lib.jea_entropy_encode.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp]
     lib.jea_entropy_decode.argtypes = [vp, vp, vp, vp, sz, sz, vp]
     lib.jea_idct_dequant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_remove_stuffing.argtypes = [vp, vp, sz, vp, c.POINTER(sz)]
     lib.jea_rgb_to_ycbcr.argtypes = [vp, vp, sz, vp]
     lib.jea_ycbcr_to_rgb.argtypes = [vp, vp, sz, vp]
     lib.jea_rgb_to_ycbcr_host.argtypes = [vp, vp, sz, vp]
@@ -98,6 +99,8 @@ def load_library():
     lib.jea_huffman_encode_blocks.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.jea_stream_upload.argtypes = [vp, vp, sz]
     lib.jea_huffman_decode_block.argtypes = [vp, c.c_uint64, i32, c.POINTER(c.c_int16), vp, c.POINTER(c.c_uint64)]
+    lib.jea_huffman_encode_rle.argtypes = [vp, c.c_int16, vp, vp, sz, i32, c.POINTER(c.c_uint32), vp, sz]
+    lib.jea_huffman_decode_rle.argtypes = [vp, c.c_uint64, i32, c.POINTER(c.c_int16), vp, vp, c.POINTER(sz), c.POINTER(c.c_uint64)]
     lib.jea_malloc.argtypes = [vp, sz, c.POINTER(vp)]
     lib.jea_free.argtypes = [vp, vp]
     lib.jea_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -287,6 +290,14 @@ class Context:
                                                 sizes.ctypes.data, n, mcus, coefs.data_ptr()))
         return coefs
 
+    def remove_stuffing(self, scan_with_eoi):
+        """bytes -> bytes: BitStream::removeStuffedBytes on scan data that ends with the EOI marker."""
+        d_in = self.to_device(np.frombuffer(scan_with_eoi, np.uint8))
+        d_out = self.empty(d_in.numel(), self.torch.uint8)
+        n = ctypes.c_size_t(0)
+        self._check(self.lib.jea_remove_stuffing(self.handle, d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), ctypes.byref(n)))
+        return d_out[: n.value].cpu().numpy().tobytes()
+
     def rgb_to_ycbcr(self, d_rgb):
         out = self.torch.empty_like(d_rgb)
         self.torch.cuda.synchronize(self.tdev)
@@ -347,6 +358,25 @@ class Context:
         self._check(self.lib.jea_huffman_decode_block(self.handle, start_bit, int(is_lum), ctypes.byref(dc),
                                                       zz.ctypes.data, ctypes.byref(end)))
         return zz, end.value, dc.value
+
+    def huffman_encode_rle(self, dc_difference, entries, is_lum):
+        """entries: [(run, value), ...] -> (bit length, bits as uint32 words, MSB first)."""
+        runs = np.array([e[0] for e in entries], np.uint16)
+        values = np.array([e[1] for e in entries], np.int16)
+        words = (22 + 26 * len(entries) + 31) // 32
+        bits = np.zeros(words, np.uint32)
+        length = ctypes.c_uint32(0)
+        self._check(self.lib.jea_huffman_encode_rle(self.handle, int(dc_difference), runs.ctypes.data, values.ctypes.data,
+                                                    len(entries), int(is_lum), ctypes.byref(length), bits.ctypes.data, words))
+        return length.value, bits
+
+    def huffman_decode_rle(self, start_bit, is_lum):
+        """-> (dc difference, [(run, value), ...], end bit) from the uploaded stream."""
+        runs, values = np.zeros(64, np.uint16), np.zeros(64, np.int16)
+        dc, n, end = ctypes.c_int16(0), ctypes.c_size_t(0), ctypes.c_uint64(0)
+        self._check(self.lib.jea_huffman_decode_rle(self.handle, start_bit, int(is_lum), ctypes.byref(dc), runs.ctypes.data,
+                                                    values.ctypes.data, ctypes.byref(n), ctypes.byref(end)))
+        return dc.value, [(int(runs[i]), int(values[i])) for i in range(n.value)], end.value
 
     # ---- stripes of one image ----
     def stripe_transform(self, d_rgb_stripe, w, stripe_h, lum, chrom):

@@ -130,8 +130,7 @@ __global__ __launch_bounds__(64) void huffman_decode_block_kernel(const uint8_t*
     zz[lane] = 0;
     __syncthreads();
     if (lane == 0) {
-        // scan_end = 0: stuffing has been removed by the caller (encoder.cpp:49), nothing is skipped here
-        SerialReader rd{win, first_byte, first_byte, 0, len, 0, 0, 0};
+        SerialReader rd{win, first_byte, first_byte, len, 0, 0, 0};
         rd.refill();
         rd.skip((int)(start_bit & 7));
         int last = last_dc_in;
@@ -144,6 +143,118 @@ __global__ __launch_bounds__(64) void huffman_decode_block_kernel(const uint8_t*
     }
     __syncthreads();
     zz_out[lane] = zz[lane];
+}
+
+// HuffmanEncoder::applyFinalEncoding (entropy_encoder.cpp:696-701, 715-765) for one block-channel whose
+// run-length form the caller supplies: the DC difference, then every (run, value) entry exactly as given --
+// (0, 0) is the end-of-block code, (15, 0) the zero-run code, any other entry with value 0 is the
+// reference's "Invalid runtime encoding encountered." (:748).  Entries the tables have no code for (a run
+// above 15, an amplitude of more than 10 bits, a DC difference of more than 11) index past the reference's
+// tables; here they are reported as the same error.  bits[] receives the MSB-first string, zero padded.
+__global__ __launch_bounds__(64) void huffman_encode_rle_kernel(int dc_difference, const uint16_t* __restrict__ runs,
+                                                                const int16_t* __restrict__ values, uint32_t n,
+                                                                int is_lum, const HuffTables* __restrict__ huff,
+                                                                uint32_t* __restrict__ bits, uint32_t* __restrict__ length,
+                                                                int32_t* __restrict__ status) {
+    __shared__ HuffLds h;
+    load_huff<64>(h, huff);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int cls = is_lum ? 0 : 1;
+    const uint32_t* dc_tab = h.dc[cls];
+    const uint32_t* ac_tab = h.ac[cls];
+    SlotSink sink;
+    sink.slot = bits;
+    sink.stride = 1;
+    bool ok = true;
+    {
+        const uint32_t amp = (uint32_t)(dc_difference < 0 ? -dc_difference : dc_difference) & 0xffffu;
+        uint32_t s = bit_width(amp);
+        if (s > 11) { ok = false; s = 11; }
+        const uint32_t e = dc_tab[s];
+        const uint32_t extra = (dc_difference > 0 ? amp : ~amp) & ((1u << s) - 1u);
+        sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
+    }
+    for (uint32_t i = 0; i < n && ok; ++i) {
+        const uint32_t run = runs[i];
+        const int v = values[i];
+        const uint32_t amp = (uint32_t)(v < 0 ? -v : v) & 0xffffu;
+        const uint32_t s = bit_width(amp);
+        if (s == 0) {
+            if (run != 0 && run != 15) { ok = false; break; }
+            const uint32_t e = ac_tab[run == 0 ? 0x00 : 0xF0];
+            sink.put(e & 0xffffu, e >> 16);
+        } else {
+            if (run > 15 || s > 10) { ok = false; break; }
+            const uint32_t e = ac_tab[(run << 4) | s];
+            const uint32_t extra = (v > 0 ? amp : ~amp) & ((1u << s) - 1u);
+            sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
+        }
+    }
+    sink.finish();
+    *length = sink.bits;
+    if (!ok) atomicExch(status, JEA_ERR_RANGE);
+}
+
+// HuffmanEncoder::removeFinalEncoding (entropy_encoder.cpp:703-712, 767-866) for one block-channel of an
+// unstuffed stream: the DC difference and the (run, value) entries up to and including the end-of-block
+// entry, or until 63 coefficient positions are covered.
+__global__ __launch_bounds__(64) void huffman_decode_rle_kernel(const uint8_t* __restrict__ stream, uint64_t len,
+                                                                uint64_t start_bit, int is_lum,
+                                                                const DecodeTables* __restrict__ tables,
+                                                                int32_t* __restrict__ dc_difference,
+                                                                uint16_t* __restrict__ runs, int16_t* __restrict__ values,
+                                                                uint32_t* __restrict__ n_entries,
+                                                                uint64_t* __restrict__ end_bit, int32_t* __restrict__ status) {
+    __shared__ DecodeTables t;
+    __shared__ __align__(16) uint8_t win[kStreamWin + 16];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < sizeof(DecodeTables) / 4; i += 64)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tables)[i];
+    const uint64_t first_byte = start_bit >> 3;
+    for (uint32_t i = lane; i < kStreamWin + 16; i += 64) win[i] = (first_byte + i < len) ? stream[first_byte + i] : 0;
+    __syncthreads();
+    if (lane != 0) return;
+    SerialReader rd{win, first_byte, first_byte, len, 0, 0, 0};
+    rd.refill();
+    rd.skip((int)(start_bit & 7));
+    const int cls = is_lum ? 0 : 1;
+    const DecodeTable& dct = t.tab[2 * cls];
+    const DecodeTable& act = t.tab[2 * cls + 1];
+    int err = 0;
+    rd.refill();
+    const int s = decode_symbol(rd, dct);
+    int diff = 0;
+    if (s < 0 || s > 11) err = JEA_ERR_BAD_STREAM;
+    else if (s > 0) { rd.refill(); diff = read_amplitude(rd, s); }
+    uint32_t n = 0;
+    int processed = 0;
+    while (!err) {
+        rd.refill();
+        const int sym = decode_symbol(rd, act);
+        if (sym < 0) { err = JEA_ERR_BAD_STREAM; break; }
+        int run, val;
+        if (sym == 0x00) { run = 0; val = 0; }
+        else if (sym == 0xF0) { run = 15; val = 0; }
+        else {
+            run = sym >> 4;
+            const int ss = sym & 15;
+            if (ss == 0 || ss > 10) { err = JEA_ERR_BAD_STREAM; break; }
+            rd.refill();
+            val = read_amplitude(rd, ss);
+        }
+        runs[n] = (uint16_t)run;
+        values[n] = (int16_t)val;
+        ++n;
+        processed += 1 + run;
+        if (processed > 63) { err = JEA_ERR_BAD_STREAM; break; }
+        if ((run == 0 && val == 0) || processed == 63) break;
+    }
+    if (rd.past_end()) err = JEA_ERR_BAD_STREAM;
+    if (err) atomicExch(status, err);
+    *dc_difference = diff;
+    *n_entries = n;
+    *end_bit = rd.pos * 8 - (uint64_t)rd.nbits;
 }
 
 unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -169,6 +280,17 @@ void launch_huffman_encode_blocks(hipStream_t s, const int16_t* d_zz, const int1
                                   int32_t* d_status) {
     huffman_encode_blocks_kernel<<<blocks_for(n, 64), 64, 0, s>>>(d_zz, d_prev_dc, d_is_lum, n, d_huff, d_lengths, d_bits,
                                                                   d_status);
+}
+void launch_huffman_encode_rle(hipStream_t s, int dc_difference, const uint16_t* d_runs, const int16_t* d_values, uint32_t n,
+                               bool is_lum, const HuffTables* d_huff, uint32_t* d_bits, uint32_t* d_length, int32_t* d_status) {
+    huffman_encode_rle_kernel<<<1, 64, 0, s>>>(dc_difference, d_runs, d_values, n, is_lum ? 1 : 0, d_huff, d_bits, d_length,
+                                               d_status);
+}
+void launch_huffman_decode_rle(hipStream_t s, const uint8_t* d_stream, uint64_t len, uint64_t start_bit, bool is_lum,
+                               const DecodeTables* d_tables, int32_t* d_dc_difference, uint16_t* d_runs, int16_t* d_values,
+                               uint32_t* d_n_entries, uint64_t* d_end_bit, int32_t* d_status) {
+    huffman_decode_rle_kernel<<<1, 64, 0, s>>>(d_stream, len, start_bit, is_lum ? 1 : 0, d_tables, d_dc_difference, d_runs,
+                                               d_values, d_n_entries, d_end_bit, d_status);
 }
 void launch_huffman_decode_block(hipStream_t s, const uint8_t* d_stream, uint64_t len, uint64_t start_bit, bool is_lum,
                                  int last_dc, const DecodeTables* d_tables, int16_t* d_zz, uint64_t* d_end_bit,

@@ -1222,6 +1222,40 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     return report_status(ctx, report->status, what);
 }
 
+int jea_remove_stuffing(jea_ctx* ctx, const uint8_t* d_scan, size_t len, uint8_t* d_out, size_t* out_len) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_scan || !d_out || !out_len || len == 0 || len > ((size_t)1 << 34))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_remove_stuffing: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    const DecodePlan plan = plan_entropy_decode(1, len, 1);
+    int rc;
+    if ((rc = ensure(ctx, ctx->seg_offsets, 3 * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ustream, (len + 15) / 16 * 16 + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->chunk_drops, plan.n_chunks * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->chunk_base, plan.n_chunks * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->img_drops, sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->round_flags, 4 * sizeof(uint32_t)))) return rc;
+    const uint64_t seg[3] = {0, (uint64_t)len, 0};   // offset | size | base of the unstuffed copy
+    launch_seed_words(ctx->stream, (uint64_t*)ctx->seg_offsets.ptr, seg, 3);
+    JEA_HIP(ctx, hipGetLastError());
+    const uint64_t* d_seg = (const uint64_t*)ctx->seg_offsets.ptr;
+    DecodeScratch sc{};
+    sc.ubase = d_seg + 2;
+    sc.ustream = (uint8_t*)ctx->ustream.ptr;
+    sc.chunk_drops = (uint32_t*)ctx->chunk_drops.ptr;
+    sc.chunk_base = (uint64_t*)ctx->chunk_base.ptr;
+    sc.img_drops = (uint64_t*)ctx->img_drops.ptr;
+    sc.changed = (uint32_t*)ctx->round_flags.ptr;
+    JEA_HIP(ctx, launch_unstuff(ctx->stream, d_scan, d_seg, d_seg + 1, plan, sc, ctx->d_status));
+    uint64_t drops = 0;
+    JEA_HIP(ctx, hipMemcpyAsync(&drops, sc.img_drops, sizeof(drops), hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JEA_HIP(ctx, hipMemcpyAsync(d_out, sc.ustream, len - drops, hipMemcpyDeviceToDevice, ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_len = len - (size_t)drops;
+    return JEA_OK;
+}
+
 int jea_entropy_decode(jea_ctx* ctx, const uint8_t* d_scan, const uint64_t* h_offsets, const uint64_t* h_sizes,
                        size_t n_images, size_t mcus_per_image, int16_t* d_coefs) {
     if (!ctx) return JEA_ERR_INVALID_ARG;
@@ -1398,6 +1432,66 @@ int jea_huffman_decode_block(jea_ctx* ctx, uint64_t start_bit, int is_luminance,
     int32_t dc;
     std::memcpy(&dc, h + 136, 4);
     *last_dc = (int16_t)dc;
+    return JEA_OK;
+}
+
+int jea_huffman_encode_rle(jea_ctx* ctx, int16_t dc_difference, const uint16_t* h_runs, const int16_t* h_values,
+                           size_t n_entries, int is_luminance, uint32_t* length_bits, uint32_t* h_bits,
+                           size_t bits_capacity_words) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    const size_t words = (22 + 26 * n_entries + 31) / 32;
+    if (!length_bits || !h_bits || (n_entries && (!h_runs || !h_values)) || n_entries > 4096 || bits_capacity_words < words)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_huffman_encode_rle: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    // input: [runs 2n][values 2n]; output: [bits 4*words][length 4]
+    const size_t in_half = (2 * n_entries + 15) & ~size_t(15);
+    int rc;
+    if ((rc = ensure(ctx, ctx->stage_in, 2 * in_half + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->stage_out, 4 * words + 16))) return rc;
+    uint8_t* din = (uint8_t*)ctx->stage_in.ptr;
+    uint8_t* dout = (uint8_t*)ctx->stage_out.ptr;
+    if (n_entries) {
+        JEA_HIP(ctx, hipMemcpyAsync(din, h_runs, 2 * n_entries, hipMemcpyHostToDevice, ctx->stream));
+        JEA_HIP(ctx, hipMemcpyAsync(din + in_half, h_values, 2 * n_entries, hipMemcpyHostToDevice, ctx->stream));
+    }
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    JEA_HIP(ctx, hipMemsetAsync(dout, 0, 4 * words + 4, ctx->stream));
+    launch_huffman_encode_rle(ctx->stream, (int)dc_difference, (const uint16_t*)din, (const int16_t*)(din + in_half),
+                              (uint32_t)n_entries, is_luminance != 0, ctx->d_huff, (uint32_t*)dout, (uint32_t*)(dout + 4 * words),
+                              ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipMemcpyAsync(h_bits, dout, 4 * words, hipMemcpyDeviceToHost, ctx->stream));
+    JEA_HIP(ctx, hipMemcpyAsync(length_bits, dout + 4 * words, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_status(ctx, ctx->d_status, "jea_huffman_encode_rle");
+}
+
+int jea_huffman_decode_rle(jea_ctx* ctx, uint64_t start_bit, int is_luminance, int16_t* dc_difference,
+                           uint16_t h_runs[64], int16_t h_values[64], size_t* n_entries, uint64_t* end_bit) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!dc_difference || !h_runs || !h_values || !n_entries || !end_bit || ctx->stream_len == 0 ||
+        start_bit >= 8 * (uint64_t)ctx->stream_len)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_huffman_decode_rle: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->small, 512))) return rc;
+    uint8_t* d = (uint8_t*)ctx->small.ptr;   // [runs 128][values 128][end_bit 8][dc 4][n 4]
+    JEA_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), ctx->stream));
+    launch_huffman_decode_rle(ctx->stream, (const uint8_t*)ctx->stream_copy.ptr, ctx->stream_len, start_bit, is_luminance != 0,
+                              ctx->d_decode, (int32_t*)(d + 264), (uint16_t*)d, (int16_t*)(d + 128), (uint32_t*)(d + 268),
+                              (uint64_t*)(d + 256), ctx->d_status);
+    JEA_HIP(ctx, hipGetLastError());
+    uint8_t h[272];
+    JEA_HIP(ctx, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = finish_status(ctx, ctx->d_status, "jea_huffman_decode_rle"))) return rc;
+    uint32_t n;
+    int32_t dc;
+    std::memcpy(&n, h + 268, 4);
+    std::memcpy(&dc, h + 264, 4);
+    std::memcpy(end_bit, h + 256, 8);
+    std::memcpy(h_runs, h, 2 * (size_t)n);
+    std::memcpy(h_values, h + 128, 2 * (size_t)n);
+    *n_entries = n;
+    *dc_difference = (int16_t)dc;
     return JEA_OK;
 }
 

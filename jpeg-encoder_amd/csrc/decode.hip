@@ -99,19 +99,31 @@ __device__ __forceinline__ Sums block_exclusive_scan(Sums v, Sums* lds4, Sums& t
 // Unstuffing
 // ---------------------------------------------------------------------------
 
-// Bit k of the result is set when raw byte j0 + k is a stuffed zero.
+// Bit k of the result is set when raw byte j0 + k is a stuffed zero, as bit_stream.cpp:136-147 sees it.  The
+// reference walks the scan serially: at a 0xFF it looks at the next byte, erases it when it is 0x00, and steps
+// over it when it is not -- so the byte after a 0xFF is never itself taken as the 0xFF of a pair.  In a run of
+// consecutive 0xFF bytes every second one is therefore passed over, and a 0x00 after the run goes exactly
+// when the run's length is odd.  Streams this encoder writes only ever have runs of one (every 0xFF is followed
+// by its 0x00); the rule matters for damaged streams, which must decode, or fail, as the reference's would.
+// The run that ends just before this piece is counted backwards, 4096 bytes at most: an unstuffed stream
+// with that many one-bits in a row holds no valid code word, so such a stream fails either way.
 __device__ __forceinline__ uint32_t drop_mask16(const uint8_t* __restrict__ file, uint64_t len, uint64_t scan_end,
                                                 uint64_t j0, uint8_t* bytes) {
-    uint32_t prev = (j0 >= 1 && j0 - 1 < len) ? file[j0 - 1] : 0u;
+    uint32_t odd = 0;   // length of the run of 0xFF bytes that ends at the previous byte, modulo 2
+    if (j0 >= 1 && j0 - 1 < len && file[j0 - 1] == 0xFFu) {
+        uint32_t run = 1;
+        while (run < 4096u && run < j0 && file[j0 - 1 - run] == 0xFFu) ++run;
+        odd = run & 1u;
+    }
     uint32_t mask = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const uint64_t j = j0 + k;
         const uint32_t b = j < len ? file[j] : 0x01u;
         bytes[k] = (uint8_t)b;
-        // bit_stream.cpp:137-138: only a 0xFF before the last two bytes makes the next zero vanish
-        if (j < len && b == 0u && prev == 0xFFu && j - 1 < scan_end) mask |= 1u << k;
-        prev = b;
+        // :137-138: only a 0xFF before the last two bytes makes the next zero vanish
+        if (j < len && b == 0u && odd && j - 1 < scan_end) mask |= 1u << k;
+        odd = (b == 0xFFu) ? (odd ^ 1u) : 0u;
     }
     return mask;
 }
@@ -1088,11 +1100,9 @@ struct DecodeRun {
 };
 }  // namespace
 
-hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
-                                 const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
-                                 const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
-                                 const std::function<void()>& follow_up, DecodeReport* report) {
-    hipError_t e;
+// bit_stream.cpp:136-147 for every stream of the job: count, (scan,) compact.  Clears *d_status and the round flags.
+hipError_t launch_unstuff(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
+                          const DecodePlan& p, const DecodeScratch& sc, int32_t* d_status) {
     const dim3 cgrid(p.n_chunks, p.n_images);
     unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops, sc.changed,
                                                     d_status);
@@ -1104,7 +1114,15 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
         unstuff_compact_kernel<false><<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops,
                                                                  sc.chunk_base, sc.img_drops, sc.ubase, sc.ustream);
     }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
+                                 const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
+                                 const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
+                                 const std::function<void()>& follow_up, DecodeReport* report) {
+    hipError_t e;
+    if ((e = launch_unstuff(s, d_scan, d_offsets, d_sizes, p, sc, d_status)) != hipSuccess) return e;
     if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[0], s);
     switch (p.sub_words) {
         case kSubWordsSmall:

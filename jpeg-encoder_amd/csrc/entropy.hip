@@ -687,7 +687,10 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
         own_bits = tile_bits[tile];
         const uint4 own_ff8 = tile_ff8[tile];
         my_len = has_block ? len16[b] : 0u;
-        if (status_now != 0) return;
+        // An error of an earlier launch ends this one.  JEA_ERR_CAPACITY is what other workgroups of this very
+        // launch may be raising right now: the waves of a workgroup could see it differently, and an early exit
+        // of some of them would leave the sums below incomplete -- so that one is left to the per-tile check.
+        if (status_now != 0 && status_now != JEA_ERR_CAPACITY) return;
         // one scan for both: the runs' bit totals (a) and the lengths of this tile's strings (b)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         uint32_t incl_a = run_bits, incl_b = my_len;

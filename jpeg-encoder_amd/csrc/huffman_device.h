@@ -175,23 +175,22 @@ __device__ __forceinline__ uint64_t ff_places(uint32_t w0, uint32_t w1, uint32_t
     return t;
 }
 
+// Bit reader over a stream from which the stuffed zeros have already been removed (the per-block entry points:
+// their callers unstuff first, as encoder.cpp:49 does).
 struct SerialReader {
-    const uint8_t* lds;     // staged raw bytes [base, base + kStreamWin + 16)
-    uint64_t base;          // file-relative index of lds[0]
-    uint64_t pos;           // next raw byte to take
-    uint64_t scan_end;      // file length - 2: stuffing is only removed before this index (bit_stream.cpp:137)
-    uint64_t len;           // file length
+    const uint8_t* lds;     // staged bytes [base, base + kStreamWin + 16)
+    uint64_t base;          // stream index of lds[0]
+    uint64_t pos;           // next byte to take
+    uint64_t len;           // stream length
     uint64_t buf;           // bit buffer, MSB first
     int nbits;              // valid bits in buf
-    int phantom;            // zero bytes appended after the end of the file
+    int phantom;            // zero bytes appended after the end of the stream
     __device__ __forceinline__ uint32_t raw(uint64_t i) const { return i < len ? lds[i - base] : 0u; }
     __device__ __forceinline__ void refill() {
         while (nbits <= 56) {
             uint32_t b = 0;
             if (pos < len) {
                 b = raw(pos);
-                // bit_stream.cpp:138: a 0x00 that follows a 0xFF is dropped
-                if (b == 0xFFu && pos < scan_end && raw(pos + 1) == 0x00u) ++pos;
             } else {
                 ++phantom;
             }

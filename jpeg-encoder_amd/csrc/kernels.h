@@ -232,6 +232,11 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const std::function<void()>& follow_up, DecodeReport* report);
 
+// The decoder's first step on its own: the unstuffed copy of every stream (sc.ustream at sc.ubase[i]) and the
+// number of dropped bytes per stream (sc.img_drops).  Needs sc.chunk_drops, chunk_base, img_drops, ubase, ustream, changed.
+hipError_t launch_unstuff(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
+                          const DecodePlan& plan, const DecodeScratch& sc, int32_t* d_status);
+
 // For streams that the standard rounds did not settle: more rounds (waiting on the stream after each),
 // then the write pass, `follow_up` and the report again, and a final wait.
 hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
@@ -273,6 +278,14 @@ void launch_huffman_encode_blocks(hipStream_t s, const int16_t* d_zz, const int1
 void launch_huffman_decode_block(hipStream_t s, const uint8_t* d_stream, uint64_t len, uint64_t start_bit, bool is_lum,
                                  int last_dc, const DecodeTables* d_tables, int16_t* d_zz, uint64_t* d_end_bit,
                                  int32_t* d_last_dc, int32_t* d_status);
+
+// Run-length form in and out (what the reference hands to / gets from its final-encoding step).
+// d_bits must hold (22 + 26 * n + 31) / 32 words; d_runs / d_values of the decoder 64 entries each.
+void launch_huffman_encode_rle(hipStream_t s, int dc_difference, const uint16_t* d_runs, const int16_t* d_values, uint32_t n,
+                               bool is_lum, const HuffTables* d_huff, uint32_t* d_bits, uint32_t* d_length, int32_t* d_status);
+void launch_huffman_decode_rle(hipStream_t s, const uint8_t* d_stream, uint64_t len, uint64_t start_bit, bool is_lum,
+                               const DecodeTables* d_tables, int32_t* d_dc_difference, uint16_t* d_runs, int16_t* d_values,
+                               uint32_t* d_n_entries, uint64_t* d_end_bit, int32_t* d_status);
 
 void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc);
 void launch_ycbcr_to_rgb(hipStream_t s, const uint8_t* d_ycc, size_t n_pixels, uint8_t* d_rgb);

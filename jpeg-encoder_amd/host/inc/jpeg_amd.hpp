@@ -16,14 +16,16 @@
 // so code written against the reference (examples/encode-decode.cpp:102-118)
 // compiles against this header unchanged.
 //
-// What is different underneath: Encoder::encode / ::decode do not loop over
-// blocks on the host.  Each injected component reports a device capability; when
-// all four have one, the whole image goes through jea_encode_host /
+// What is different underneath: each injected component reports a device
+// capability; when all four have one, Encoder::encode / ::decode do not loop over
+// blocks on the host but send the whole image through jea_encode_host /
 // jea_decode_host in a handful of kernel launches.  The per-block public methods
 // (map, transform, quantise, encode, ...) are kept and also run on the GPU, one
 // small launch per call; they exist for unit tests and API compatibility, not
-// for speed.  A component without a device implementation makes encode/decode
-// fail with the reference's error convention ("[Error]: ..." on stdout).
+// for speed.  When a component without a device capability is injected (a user's
+// subclass), encode / decode fall back to the reference's loop over blocks
+// (encoder.cpp:19-28, 52-59): the user's virtuals run on the host, the
+// library's components through their per-block entry points.
 #ifndef JPEG_AMD_HPP_
 #define JPEG_AMD_HPP_
 
@@ -188,8 +190,8 @@ private:
 
 // ---- device capabilities ---------------------------------------------------------
 /* What a component contributes to the fused GPU path.  `none` means the component
-   has no device implementation: the encoder then refuses to run (there is no host
-   fallback for image arithmetic in this build). */
+   has no device implementation (the default of the abstract bases, hence of any user
+   subclass): the encoder then takes the per-block path of the reference. */
 enum class DeviceColourMapping { none, rgbToYCbCr, rgbPassThrough };
 enum class DeviceTransform { none, separatedFloat };
 enum class DeviceEntropyCoding { none, annexKHuffman };
@@ -309,6 +311,9 @@ struct RunLengthEncodedBlockChannelData {
     std::vector<RunLengthEncodedACCoefficient> m_acCoefficients;
 };
 
+/* entropy_encoder.hpp:31-52: non-virtual encode / decode around a virtual final-encoding step that
+   works on the run-length form of a block-channel.  A subclass written against the reference
+   (overriding applyFinalEncoding / removeFinalEncoding / encodeHeaderEntropyTables) compiles unchanged. */
 class EntropyEncoder {
 public:
     EntropyEncoder() = default;
@@ -318,26 +323,41 @@ public:
     EntropyEncoder& operator=(EntropyEncoder const&&) = delete;
     virtual ~EntropyEncoder() = default;
 
-    /* Per-block entry points of the reference (entropy_encoder.hpp:40-41): natural-order
-       coefficients in, bits appended to / read from the stream, DC predictor updated. */
-    virtual void encode(QuantisedBlockChannelData const& input, int16_t& lastDCValue, BitStream& outputStream,
-                        bool isLuminanceComponent) const = 0;
-    virtual QuantisedBlockChannelData decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
-                                             int16_t& lastDCValue, bool isLuminanceComponent) const = 0;
+    /* Natural-order coefficients in, bits appended to / read from the stream, DC predictor updated
+       (entropy_encoder.cpp:3-13). */
+    void encode(QuantisedBlockChannelData const& input, int16_t& lastDCValue, BitStream& outputStream,
+                bool isLuminanceComponent) const;
+    QuantisedBlockChannelData decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
+                                     int16_t& lastDCValue, bool isLuminanceComponent) const;
     virtual void encodeHeaderEntropyTables(BitStream& outputStream) const = 0;
     virtual DeviceEntropyCoding deviceCapability() const { return DeviceEntropyCoding::none; }
+
+private:
+    QuantisedBlockChannelData mapFromGridToZigZag(QuantisedBlockChannelData const& input) const;
+    QuantisedBlockChannelData mapFromZigZagToGrid(QuantisedBlockChannelData const& input) const;
+    RunLengthEncodedBlockChannelData applyRunLengthEncoding(QuantisedBlockChannelData const& input, int16_t& lastDCValue) const;
+    QuantisedBlockChannelData removeRunLengthEncoding(RunLengthEncodedBlockChannelData const& input, int16_t& lastDCValue) const;
+
+protected:
+    virtual void applyFinalEncoding(RunLengthEncodedBlockChannelData const& input, BitStream& outputStream,
+                                    bool isLuminanceComponent) const = 0;
+    virtual RunLengthEncodedBlockChannelData removeFinalEncoding(BitStream const& inputStream,
+                                                                 BitStreamReadProgress& readProgress,
+                                                                 bool isLuminanceComponent) const = 0;
 };
 
-/* Annex-K Huffman coding; symbol generation, code lookup and bit packing run on the GPU. */
+/* Annex-K Huffman coding; code lookup and bit assembly run on the GPU. */
 class HuffmanEncoder : public EntropyEncoder {
 public:
     HuffmanEncoder();
-    void encode(QuantisedBlockChannelData const& input, int16_t& lastDCValue, BitStream& outputStream,
-                bool isLuminanceComponent) const override;
-    QuantisedBlockChannelData decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
-                                     int16_t& lastDCValue, bool isLuminanceComponent) const override;
     void encodeHeaderEntropyTables(BitStream& outputStream) const override;
     DeviceEntropyCoding deviceCapability() const override { return DeviceEntropyCoding::annexKHuffman; }
+
+protected:
+    void applyFinalEncoding(RunLengthEncodedBlockChannelData const& input, BitStream& outputStream,
+                            bool isLuminanceComponent) const override;
+    RunLengthEncodedBlockChannelData removeFinalEncoding(BitStream const& inputStream, BitStreamReadProgress& readProgress,
+                                                         bool isLuminanceComponent) const override;
 };
 
 // ---- encoder ---------------------------------------------------------------------
@@ -359,7 +379,10 @@ public:
 
 private:
     bool virtual supportsSaving() const = 0;
-    void requireDevicePath() const;
+    void requireComponents() const;
+    bool allOnDevice() const;
+    void encodePerBlock(BitmapImageRGB const& inputImage, JPEGImage& outputImage);
+    void decodePerBlock(JPEGImage& inputImage, BitmapImageRGB& outputImage);
     jea_ctx* context();
 
     std::unique_ptr<ColourMapper> m_colourMapper;

@@ -9,6 +9,7 @@
 #include <iostream>
 #include <atomic>
 #include <mutex>
+#include <typeinfo>
 #include <stdexcept>
 
 #include "../../../include/jpegenc_amd.h"
@@ -474,34 +475,110 @@ void HuffmanEncoder::encodeHeaderEntropyTables(BitStream& outputStream) const {
     for (size_t i = 173; i < 593; ++i) outputStream.pushByte(header[i]);
 }
 
-void HuffmanEncoder::encode(QuantisedBlockChannelData const& input, int16_t& lastDCValue, BitStream& outputStream,
+// entropy_encoder.cpp:3-13: zig-zag, run-length form, then the subclass's final encoding -- and back.
+void EntropyEncoder::encode(QuantisedBlockChannelData const& input, int16_t& lastDCValue, BitStream& outputStream,
                             bool isLuminanceComponent) const {
-    int16_t zz[64];
-    for (size_t k = 0; k < 64; ++k) zz[k] = input.m_data[kZigzag[k]];  // layout change only
-    const uint8_t cls = isLuminanceComponent ? 1 : 0;
-    uint16_t length = 0;
-    uint32_t bits[52];
+    applyFinalEncoding(applyRunLengthEncoding(mapFromGridToZigZag(input), lastDCValue), outputStream, isLuminanceComponent);
+}
+
+QuantisedBlockChannelData EntropyEncoder::decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
+                                                 int16_t& lastDCValue, bool isLuminanceComponent) const {
+    return mapFromZigZagToGrid(removeRunLengthEncoding(removeFinalEncoding(inputStream, readProgress, isLuminanceComponent),
+                                                       lastDCValue));
+}
+
+// :15-92 -- a change of layout only
+QuantisedBlockChannelData EntropyEncoder::mapFromGridToZigZag(QuantisedBlockChannelData const& input) const {
+    QuantisedBlockChannelData out;
+    for (size_t k = 0; k < 64; ++k) out.m_data[k] = input.m_data[kZigzag[k]];
+    return out;
+}
+QuantisedBlockChannelData EntropyEncoder::mapFromZigZagToGrid(QuantisedBlockChannelData const& input) const {
+    QuantisedBlockChannelData out;
+    for (size_t k = 0; k < 64; ++k) out.m_data[kZigzag[k]] = input.m_data[k];
+    return out;
+}
+
+// :94-120.  An entry is made for every non-zero coefficient and for every sixteenth zero in a row; when the
+// block ends in a zero, the entries of trailing zeros go and the end-of-block entry (0, 0) comes instead.
+RunLengthEncodedBlockChannelData EntropyEncoder::applyRunLengthEncoding(QuantisedBlockChannelData const& input,
+                                                                        int16_t& lastDCValue) const {
+    RunLengthEncodedBlockChannelData out;
+    out.m_dcDifference = static_cast<int16_t>(input.m_data[0] - lastDCValue);
+    lastDCValue = input.m_data[0];
+    size_t zeros = 0;
+    for (size_t k = 1; k < 64; ++k) {
+        const int16_t v = input.m_data[k];
+        if (v == 0 && zeros < 15) {
+            ++zeros;
+            continue;
+        }
+        out.m_acCoefficients.push_back({zeros, v});
+        zeros = 0;
+    }
+    if (input.m_data[63] == 0) {
+        while (!out.m_acCoefficients.empty() && out.m_acCoefficients.back().m_value == 0) out.m_acCoefficients.pop_back();
+        out.m_acCoefficients.push_back({0, 0});
+    }
+    return out;
+}
+
+// :122-144.  Every entry but the LAST is restored (:129), so a block that ends without the end-of-block entry
+// loses its final coefficient -- kept, the decoded bitmaps depend on it.
+QuantisedBlockChannelData EntropyEncoder::removeRunLengthEncoding(RunLengthEncodedBlockChannelData const& input,
+                                                                  int16_t& lastDCValue) const {
+    QuantisedBlockChannelData out;
+    out.m_data.fill(0);
+    out.m_data[0] = static_cast<int16_t>(input.m_dcDifference + lastDCValue);
+    lastDCValue = out.m_data[0];
+    size_t at = 1;
+    for (size_t i = 0; i + 1 < input.m_acCoefficients.size(); ++i) {
+        at += input.m_acCoefficients[i].m_runLength;
+        if (at < 64) out.m_data[at] = input.m_acCoefficients[i].m_value;
+        ++at;
+    }
+    return out;
+}
+
+// :696-701, 715-765 on the GPU: Huffman codes and amplitude bits of the entries as they are given.
+void HuffmanEncoder::applyFinalEncoding(RunLengthEncodedBlockChannelData const& input, BitStream& outputStream,
+                                        bool isLuminanceComponent) const {
+    const size_t n = input.m_acCoefficients.size();
+    std::vector<uint16_t> runs(n);
+    std::vector<int16_t> values(n);
+    for (size_t i = 0; i < n; ++i) {
+        // a run that does not fit the interface is no valid run either way (the reference narrows it to 8 bits, :733)
+        runs[i] = static_cast<uint16_t>(std::min<size_t>(input.m_acCoefficients[i].m_runLength, 0xffff));
+        values[i] = input.m_acCoefficients[i].m_value;
+    }
+    std::vector<uint32_t> bits((22 + 26 * n + 31) / 32);
+    uint32_t length = 0;
     {
         std::lock_guard<std::mutex> lock(g_component_mutex);
         jea_ctx* ctx = componentContext();
-        check(ctx, jea_huffman_encode_blocks(ctx, zz, &lastDCValue, &cls, 1, &length, bits));
+        check(ctx, jea_huffman_encode_rle(ctx, input.m_dcDifference, runs.data(), values.data(), n, isLuminanceComponent ? 1 : 0,
+                                          &length, bits.data(), bits.size()));
     }
-    lastDCValue = zz[0];
     for (size_t done = 0; done < length;) {
-        const size_t n = std::min<size_t>(16, length - done);
+        const size_t take = std::min<size_t>(16, length - done);
         const size_t word = done / 32, shift = done % 32;
-        const uint64_t two = (static_cast<uint64_t>(bits[word]) << 32) | (word + 1 < 52 ? bits[word + 1] : 0u);
-        outputStream.pushBitsu16(static_cast<uint16_t>((two << shift) >> (64 - n)), n);
-        done += n;
+        const uint64_t two = (static_cast<uint64_t>(bits[word]) << 32) | (word + 1 < bits.size() ? bits[word + 1] : 0u);
+        outputStream.pushBitsu16(static_cast<uint16_t>((two << shift) >> (64 - take)), take);
+        done += take;
     }
 }
 
-QuantisedBlockChannelData HuffmanEncoder::decode(BitStream const& inputStream, BitStreamReadProgress& readProgress,
-                                                 int16_t& lastDCValue, bool isLuminanceComponent) const {
+// :703-712, 767-866 on the GPU.
+RunLengthEncodedBlockChannelData HuffmanEncoder::removeFinalEncoding(BitStream const& inputStream,
+                                                                     BitStreamReadProgress& readProgress,
+                                                                     bool isLuminanceComponent) const {
     // the GPU keeps a copy of the stream; it is refreshed when the contents differ from the uploaded ones
     static bool uploaded = false;
     static uint64_t uploadedRevision = 0;
-    int16_t zz[64];
+    uint16_t runs[64];
+    int16_t values[64];
+    int16_t dcDifference = 0;
+    size_t n = 0;
     uint64_t endBit = 0;
     {
         std::lock_guard<std::mutex> lock(g_component_mutex);
@@ -511,13 +588,14 @@ QuantisedBlockChannelData HuffmanEncoder::decode(BitStream const& inputStream, B
             uploaded = true;
             uploadedRevision = inputStream.revision();
         }
-        check(ctx, jea_huffman_decode_block(ctx, 8 * static_cast<uint64_t>(readProgress.currentByte) + readProgress.currentBit,
-                                            isLuminanceComponent ? 1 : 0, &lastDCValue, zz, &endBit));
+        check(ctx, jea_huffman_decode_rle(ctx, 8 * static_cast<uint64_t>(readProgress.currentByte) + readProgress.currentBit,
+                                          isLuminanceComponent ? 1 : 0, &dcDifference, runs, values, &n, &endBit));
     }
     readProgress.currentByte = static_cast<size_t>(endBit / 8);
     readProgress.currentBit = static_cast<size_t>(endBit % 8);
-    QuantisedBlockChannelData out;
-    for (size_t k = 0; k < 64; ++k) out.m_data[kZigzag[k]] = zz[k];
+    RunLengthEncodedBlockChannelData out;
+    out.m_dcDifference = dcDifference;
+    for (size_t i = 0; i < n; ++i) out.m_acCoefficients.push_back({runs[i], values[i]});
     return out;
 }
 
@@ -548,15 +626,73 @@ jea_ctx* Encoder::context() {
     return m_context;
 }
 
-void Encoder::requireDevicePath() const {
+void Encoder::requireComponents() const {
     if (!m_colourMapper || !m_discreteCosineTransformer || !m_quantiser || !m_entropyEncoder)
         throw std::runtime_error("Encoder is missing a component");
-    if (m_colourMapper->deviceCapability() == DeviceColourMapping::none)
-        throw std::runtime_error("The injected colour mapper has no GPU implementation");
-    if (m_discreteCosineTransformer->deviceCapability() != DeviceTransform::separatedFloat)
-        throw std::runtime_error("The injected cosine transformer has no GPU implementation");
-    if (m_entropyEncoder->deviceCapability() != DeviceEntropyCoding::annexKHuffman)
-        throw std::runtime_error("The injected entropy encoder has no GPU implementation");
+}
+
+// The fused GPU path implements the library's own components, and only those: a subclass of one of them may
+// override any step, so the test is on the exact type as well as on the capability it reports.
+bool Encoder::allOnDevice() const {
+    auto const& mapper = *m_colourMapper;
+    auto const& transformer = *m_discreteCosineTransformer;
+    auto const& coder = *m_entropyEncoder;
+    const bool knownMapper = (typeid(mapper) == typeid(RGBToYCbCrMapper) && mapper.deviceCapability() == DeviceColourMapping::rgbToYCbCr) ||
+                             (typeid(mapper) == typeid(RGBToRGBMapper) && mapper.deviceCapability() == DeviceColourMapping::rgbPassThrough);
+    return knownMapper &&
+           typeid(transformer) == typeid(SeparatedDiscreteCosineTransformer) && transformer.deviceCapability() == DeviceTransform::separatedFloat &&
+           typeid(coder) == typeid(HuffmanEncoder) && coder.deviceCapability() == DeviceEntropyCoding::annexKHuffman;
+}
+
+// Encoder::encode as the reference runs it (encoder.cpp:16-37, header :74-138): every step through the injected
+// components' per-block methods, so that a user's subclass is honoured.  The library's own components do their
+// arithmetic on the GPU, one small launch per call -- a path for correctness, not for speed.
+void Encoder::encodePerBlock(BitmapImageRGB const& inputImage, JPEGImage& outputImage) {
+    BitStream& stream = outputImage.m_compressedImageData;
+    uint16_t ones[64];
+    for (auto& v : ones) v = 1;
+    uint8_t fixed[JEA_HEADER_BYTES];
+    jea_write_header(fixed, inputImage.m_width, inputImage.height, ones, ones);
+    for (size_t i = 0; i < 20; ++i) stream.pushByte(fixed[i]);            // SOI, APP0
+    m_quantiser->encodeHeaderQuantisationTables(stream);                   // DQT
+    for (size_t i = 154; i < 173; ++i) stream.pushByte(fixed[i]);         // SOF0
+    m_entropyEncoder->encodeHeaderEntropyTables(stream);                   // DHT, the injected coder's
+    for (size_t i = 593; i < JEA_HEADER_BYTES; ++i) stream.pushByte(fixed[i]);   // SOS
+    const size_t startOfScanData = stream.getSize();
+    InputBlockGrid grid(inputImage);
+    std::array<int16_t, 3> lastDC = {0, 0, 0};
+    for (auto block = grid.begin(); block != grid.end(); ++block) {
+        const ColourMappedBlockData mapped = m_colourMapper->map(*block);
+        for (size_t channel = 0; channel < 3; ++channel) {
+            const bool lum = m_colourMapper->isLuminanceComponent(static_cast<uint8_t>(channel));
+            const DctBlockChannelData dct = m_discreteCosineTransformer->transform(mapped.m_data[channel]);
+            m_entropyEncoder->encode(m_quantiser->quantise(dct, lum), lastDC[channel], stream, lum);
+        }
+    }
+    stream.stuffBytes(startOfScanData);
+    stream.pushIntoAlignment();
+    stream.pushWord(markerEndOfImageSegmentEOI);
+}
+
+// Encoder::decode likewise (encoder.cpp:46-66); the header has been validated by the caller.
+void Encoder::decodePerBlock(JPEGImage& inputImage, BitmapImageRGB& outputImage) {
+    OutputBlockGrid grid(inputImage.m_width, inputImage.m_height);
+    BitStreamReadProgress progress;
+    progress.currentByte = JEA_HEADER_BYTES;
+    BitStream& stream = inputImage.m_compressedImageData;
+    stream.removeStuffedBytes(progress);
+    std::array<int16_t, 3> lastDC = {0, 0, 0};
+    while (!grid.atEnd()) {
+        ColourMappedBlockData block;
+        for (size_t channel = 0; channel < 3; ++channel) {
+            const bool lum = m_colourMapper->isLuminanceComponent(static_cast<uint8_t>(channel));
+            const QuantisedBlockChannelData quantised = m_entropyEncoder->decode(stream, progress, lastDC[channel], lum);
+            block.m_data[channel] = m_discreteCosineTransformer->inverseTransform(m_quantiser->dequantise(quantised, lum));
+        }
+        grid.processNextBlock(m_colourMapper->unmap(block));
+    }
+    if (stream.readNextAlignedWord(progress) != markerEndOfImageSegmentEOI) throw std::runtime_error("Failed to find EOI marker");
+    outputImage = grid.getBitmapRGB();
 }
 
 // Encoder::encode of the reference (encoder.cpp:14-42): same outputs, same
@@ -564,10 +700,18 @@ void Encoder::requireDevicePath() const {
 void Encoder::encode(BitmapImageRGB const& inputImage, JPEGImage& outputImage) {
     try {
         outputImage.m_compressedImageData.clearStream();
-        requireDevicePath();
+        requireComponents();
         if (inputImage.m_width == 0 || inputImage.height == 0 ||
             inputImage.m_imageData.size() != static_cast<size_t>(inputImage.m_width) * inputImage.height)
             throw std::runtime_error("Input bitmap is empty or inconsistent");
+        if (!allOnDevice()) {
+            encodePerBlock(inputImage, outputImage);
+            outputImage.m_width = inputImage.m_width;
+            outputImage.m_height = inputImage.height;
+            outputImage.m_fileSize = outputImage.m_compressedImageData.getSize();
+            outputImage.m_supportsSaving = supportsSaving();
+            return;
+        }
         jea_ctx* ctx = context();
         // worst case is some 19 bytes per pixel: the buffer is left uninitialised, so that only the pages the
         // file really takes are ever touched
@@ -592,7 +736,7 @@ void Encoder::encode(BitmapImageRGB const& inputImage, JPEGImage& outputImage) {
 // reference's messages; the output is only replaced on success.
 void Encoder::decode(JPEGImage inputImage, BitmapImageRGB& outputImage) {
     try {
-        requireDevicePath();
+        requireComponents();
         BitStream& stream = inputImage.m_compressedImageData;
         const size_t len = stream.committedBytes();
         uint16_t headerWidth = 0, headerHeight = 0;
@@ -602,6 +746,10 @@ void Encoder::decode(JPEGImage inputImage, BitmapImageRGB& outputImage) {
         outputImage.height = headerHeight;  // encoder.cpp:199-200; overwritten below on success
         outputImage.m_width = headerWidth;
         if (inputImage.m_width == 0 || inputImage.m_height == 0) throw std::runtime_error("JPEG image has no dimensions");
+        if (!allOnDevice()) {
+            decodePerBlock(inputImage, outputImage);
+            return;
+        }
         jea_ctx* ctx = context();
         // The library touches the caller's pixels only when the whole decode has succeeded, so an output
         // that already has the right size is decoded into directly; otherwise into a fresh bitmap.

@@ -161,23 +161,113 @@ int main(int argc, char** argv) {
                              std::memcmp(fused.m_imageData.data(), perBlock.m_imageData.data(), fused.m_imageData.size() * 3) == 0;
         std::printf("passthrough_decode_matches %d\n", int(sameDec));
     }
-    {   // an injected component without a GPU implementation: error printed, no throw, no output
-        class HostOnlyTransform final : public jpeg::DiscreteCosineTransformer {
+    {   // a user's colour mapper (a subclass the library knows nothing about): the encoder falls back to the
+        // reference's loop over blocks and calls the user's virtuals; this one restates the pass-through
+        // mapping, so its files must equal those of the library's RGBToRGBMapper on the fused path
+        class UserMapper final : public jpeg::ColourMapper {
         protected:
-            jpeg::DctBlockChannelData applyTransform(std::array<int8_t, jpeg::BlockGrid::blockElements> const&) const override { return {}; }
-            std::array<int8_t, jpeg::BlockGrid::blockElements> applyInverseTransform(jpeg::DctBlockChannelData const&) const override { return {}; }
-        };
-        class Custom final : public jpeg::Encoder {
+            jpeg::ColourMappedBlockData applyMapping(jpeg::BlockGrid::Block const& in) const override {
+                jpeg::ColourMappedBlockData out;
+                for (size_t i = 0; i < in.m_blockPixelData.size(); ++i) {
+                    out.m_data[0][i] = in.m_blockPixelData[i].r;
+                    out.m_data[1][i] = in.m_blockPixelData[i].g;
+                    out.m_data[2][i] = in.m_blockPixelData[i].b;
+                }
+                ++calls;
+                return out;
+            }
+            jpeg::BlockGrid::Block reverseMapping(jpeg::ColourMappedBlockData const& in) const override {
+                jpeg::BlockGrid::Block out;
+                for (size_t i = 0; i < out.m_blockPixelData.size(); ++i)
+                    out.m_blockPixelData[i] = {in.m_data[0][i], in.m_data[1][i], in.m_data[2][i]};
+                return out;
+            }
+            bool componentIsLuminance(uint8_t) const override { return true; }
         public:
-            Custom() : Encoder(std::make_unique<jpeg::RGBToYCbCrMapper>(), std::make_unique<HostOnlyTransform>(),
-                               std::make_unique<jpeg::Quantiser>(50), std::make_unique<jpeg::HuffmanEncoder>()) {}
+            mutable size_t calls = 0;
+        };
+        class MyNewEncoder final : public jpeg::Encoder {   // the shape of the reference's readme example
+        public:
+            MyNewEncoder(int quality, std::unique_ptr<jpeg::ColourMapper> mapper)
+                : Encoder(std::move(mapper), std::make_unique<jpeg::SeparatedDiscreteCosineTransformer>(),
+                          std::make_unique<jpeg::Quantiser>(quality), std::make_unique<jpeg::HuffmanEncoder>()) {}
         private:
             bool supportsSaving() const override { return false; }
-        } custom;
-        jpeg::BitmapImageRGB bmp = make_image(16, 16, 0, 1);
-        jpeg::JPEGImage jpg;
-        custom.encode(bmp, jpg);
-        std::printf("no_device_path_size %zu\n", jpg.m_compressedImageData.getSize());
+        };
+        auto userMapper = std::make_unique<UserMapper>();
+        UserMapper const* counter = userMapper.get();
+        MyNewEncoder user(65, std::move(userMapper)), library(65, std::make_unique<jpeg::RGBToRGBMapper>());
+        jpeg::BitmapImageRGB bmp = make_image(45, 30, 1, 3);
+        jpeg::JPEGImage a, b;
+        user.encode(bmp, a);
+        library.encode(bmp, b);
+        const bool same = a.m_compressedImageData.getSize() == b.m_compressedImageData.getSize() && a.m_fileSize == b.m_fileSize &&
+                          std::memcmp(a.m_compressedImageData.getDataPtr(), b.m_compressedImageData.getDataPtr(), a.m_compressedImageData.getSize()) == 0;
+        std::printf("user_mapper_encode_matches %d blocks_mapped %zu saving %d jpeg %016llx\n", int(same), counter->calls, int(a.m_supportsSaving),
+                    (unsigned long long)fnv(a.m_compressedImageData.getDataPtr(), a.m_compressedImageData.getSize(), basis));
+        jpeg::BitmapImageRGB da, db;
+        user.decode(a, da);
+        library.decode(b, db);
+        const bool sameDec = da.m_imageData.size() == db.m_imageData.size() && da.m_width == 45 && da.height == 30 &&
+                             std::memcmp(da.m_imageData.data(), db.m_imageData.data(), da.m_imageData.size() * 3) == 0;
+        std::printf("user_mapper_decode_matches %d rgb %016llx\n", int(sameDec),
+                    (unsigned long long)fnv(reinterpret_cast<const uint8_t*>(da.m_imageData.data()), da.m_imageData.size() * 3, basis));
+    }
+    {   // a subclass of HuffmanEncoder written against the reference's interface (entropy_encoder.hpp:40-51): it
+        // overrides the protected final-encoding step; encode / decode of the base class must route through it
+        class CountingHuffman final : public jpeg::HuffmanEncoder {
+        public:
+            mutable size_t encoded = 0, decoded = 0, entries = 0;
+        protected:
+            void applyFinalEncoding(jpeg::RunLengthEncodedBlockChannelData const& in, jpeg::BitStream& out, bool lum) const override {
+                ++encoded;
+                entries += in.m_acCoefficients.size();
+                HuffmanEncoder::applyFinalEncoding(in, out, lum);
+            }
+            jpeg::RunLengthEncodedBlockChannelData removeFinalEncoding(jpeg::BitStream const& in, jpeg::BitStreamReadProgress& p, bool lum) const override {
+                ++decoded;
+                return HuffmanEncoder::removeFinalEncoding(in, p, lum);
+            }
+        };
+        class WithCounting final : public jpeg::Encoder {
+        public:
+            WithCounting(std::unique_ptr<jpeg::EntropyEncoder> e)
+                : Encoder(std::make_unique<jpeg::RGBToYCbCrMapper>(), std::make_unique<jpeg::SeparatedDiscreteCosineTransformer>(),
+                          std::make_unique<jpeg::Quantiser>(75), std::move(e)) {}
+        private:
+            bool supportsSaving() const override { return true; }
+        };
+        auto coder = std::make_unique<CountingHuffman>();
+        CountingHuffman const* counter = coder.get();
+        WithCounting custom(std::move(coder));
+        jpeg::BaselineEncoder baseline(75);
+        jpeg::BitmapImageRGB bmp = make_image(29, 18, 0, 8);
+        jpeg::JPEGImage a, b;
+        custom.encode(bmp, a);
+        baseline.encode(bmp, b);
+        const bool same = a.m_compressedImageData.getSize() == b.m_compressedImageData.getSize() &&
+                          std::memcmp(a.m_compressedImageData.getDataPtr(), b.m_compressedImageData.getDataPtr(), a.m_compressedImageData.getSize()) == 0;
+        jpeg::BitmapImageRGB da, db;
+        custom.decode(a, da);
+        baseline.decode(b, db);
+        const bool sameDec = da.m_imageData.size() == db.m_imageData.size() && !da.m_imageData.empty() &&
+                             std::memcmp(da.m_imageData.data(), db.m_imageData.data(), da.m_imageData.size() * 3) == 0;
+        std::printf("user_entropy_coder encode_matches %d decode_matches %d encoded %zu decoded %zu\n", int(same), int(sameDec),
+                    counter->encoded, counter->decoded);
+        // the final-encoding step takes the entries as they are given: an entry that no code exists for is the
+        // reference's runtime error (entropy_encoder.cpp:748), printed and swallowed by encode
+        class BadEntries final : public jpeg::HuffmanEncoder {
+        protected:
+            void applyFinalEncoding(jpeg::RunLengthEncodedBlockChannelData const& in, jpeg::BitStream& out, bool lum) const override {
+                jpeg::RunLengthEncodedBlockChannelData bad = in;
+                bad.m_acCoefficients.insert(bad.m_acCoefficients.begin(), {3, 0});
+                HuffmanEncoder::applyFinalEncoding(bad, out, lum);
+            }
+        };
+        WithCounting broken(std::make_unique<BadEntries>());
+        jpeg::JPEGImage c;
+        broken.encode(bmp, c);
+        std::printf("bad_entries_done\n");
     }
     {   // wall time of the two calls a user of the classes makes, on a 3840x2160 picture
         jpeg::BitmapImageRGB bmp = make_image(3840, 2160, 0, 1234);

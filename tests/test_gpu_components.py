@@ -129,3 +129,59 @@ def test_huffman_decode_block_walk(ctx, po, jea):
             assert np.array_equal(zz, want[mcu, ch]), (mcu, ch)
     assert (bit + 7) // 8 == used
     assert want[3, 0, 63] == 0
+
+
+def _run_length_form(zz, prev_dc):
+    """entropy_encoder.cpp:94-120 restated for the test: (dc difference, [(run, value), ...])."""
+    entries, zeros = [], 0
+    for v in zz[1:]:
+        if v == 0 and zeros < 15:
+            zeros += 1
+            continue
+        entries.append((zeros, int(v)))
+        zeros = 0
+    if zz[63] == 0:
+        while entries and entries[-1][1] == 0:
+            entries.pop()
+        entries.append((0, 0))
+    return int(zz[0]) - int(prev_dc), entries
+
+
+def test_huffman_final_encoding_on_run_length_form(ctx, po, jea):
+    """jea_huffman_encode_rle / jea_huffman_decode_rle: the step a subclass of EntropyEncoder may replace
+    (entropy_encoder.hpp:50-51).  The strings must be those of the block-level entry point, which the oracle pins."""
+    lum, chrom = jea.binding.quant_tables(85)
+    rgb = po.gen_image(48, 24, 1, 33)
+    coefs = po.image_to_coefs(rgb, lum, chrom)
+    coefs[2, 1, 63] = -7                                                 # a block without EOB
+    coefs[4, 0, 1:] = 0
+    coefs[4, 0, 40] = 3                                                  # zero runs of more than 16
+    m = coefs.shape[0]
+    prev = np.zeros((m, 3), np.int16)
+    prev[1:] = coefs[:-1, :, 0]
+    is_lum = np.tile(np.array([1, 0, 0], np.uint8), m)
+    lengths, bits = ctx.huffman_encode_blocks(coefs.reshape(-1, 64), prev.reshape(-1), is_lum)
+    flat, prevs = coefs.reshape(-1, 64), prev.reshape(-1)
+    for i in range(flat.shape[0]):
+        diff, entries = _run_length_form(flat[i], prevs[i])
+        n, words = ctx.huffman_encode_rle(diff, entries, is_lum[i])
+        assert n == lengths[i], i
+        assert np.array_equal(words[: (n + 31) // 32], bits[i][: (n + 31) // 32]), i
+    # and back: the stream of all blocks, entry lists as they were encoded
+    scan, _ = po.coefs_to_scan(coefs)
+    ctx.stream_upload(scan.replace(b"\xff\x00", b"\xff") + b"\x00\x00")
+    bit = 0
+    for i in range(flat.shape[0]):
+        diff, entries = _run_length_form(flat[i], prevs[i])
+        got_diff, got_entries, bit = ctx.huffman_decode_rle(bit, is_lum[i])
+        assert (got_diff, got_entries) == (diff, entries), i
+    assert bit == int(lengths.sum())
+    # entries are taken as given: a zero value with a run other than 0 or 15 is the reference's runtime error
+    with pytest.raises(jea.binding.JeaError) as e:
+        ctx.huffman_encode_rle(0, [(3, 0), (0, 0)], True)
+    assert e.value.code == 4 and e.value.message == "Invalid runtime encoding encountered."
+    with pytest.raises(jea.binding.JeaError):
+        ctx.huffman_encode_rle(0, [(16, 5)], True)
+    # explicit zero-run entries in the tail and no end-of-block entry: encoded all the same
+    n, words = ctx.huffman_encode_rle(-3, [(15, 0), (15, 0)], False)
+    assert n == 2 + 2 + 10 + 10   # chrominance: DC size-2 code (2 bits) + 2 amplitude bits, two 10-bit ZRL codes

@@ -454,6 +454,55 @@ def test_decode_damaged_streams_agree_with_oracle(ctx, po, jea):
     assert outcomes["both fail"] > 0 and outcomes["both decode"] > 0, outcomes
 
 
+def test_decode_runs_of_ff_before_a_stuffed_zero(ctx, po, jea):
+    """bit_stream.cpp:136-147 steps over the byte after a 0xFF that is not followed by 0x00, so in FF FF 00 the zero
+    stays and in FF FF FF 00 it goes.  Streams damaged that way must decode, or fail, as the oracle's do -- also
+    where the run of 0xFF bytes crosses the 16-byte pieces and 4096-byte chunks the unstuffing kernels work in."""
+    w, h, quality = 256, 192, 100
+    lum, chrom = jea.binding.quant_tables(quality)
+    jpeg = po.encode(po.gen_image(w, h, 1, 17), quality)                  # noise at full quality: many stuffed pairs
+    pairs = [i for i in range(700, len(jpeg) - 8) if jpeg[i] == 0xFF and jpeg[i + 1] == 0x00]
+    assert len(pairs) > 200
+    near_16 = [i for i in pairs if (i - 607) % 16 in (0, 1, 15)]
+    near_4096 = sorted(pairs, key=lambda i: min((i - 607) % 4096, 4096 - (i - 607) % 4096))[:6]
+    variants = []
+    for i in pairs[:24] + near_16[:24] + near_4096:
+        for run in (1, 2, 3, 4, 17):
+            bad = bytearray(jpeg)
+            bad[i - run: i] = b"\xff" * run                              # FF x (run + 1), then 00
+            variants.append(bytes(bad))
+        bad = bytearray(jpeg)
+        bad[i - 2: i] = b"\xff\x01"                                      # FF 01 FF 00: the pair stays a pair
+        variants.append(bytes(bad))
+    variants.append(jpeg[:607] + b"\xff" * 9000 + b"\x00" + jpeg[700:])    # a run longer than the look-back: fails either way
+    for v in variants:
+        # the unstuffed stream itself, byte for byte ...
+        buf = np.frombuffer(v[607:], np.uint8).copy()
+        n = po.LIB.jo_remove_stuffing(buf.ctypes.data, 0, buf.size)
+        assert ctx.remove_stuffing(v[607:]) == buf[:n].tobytes()
+        # ... and what the decoders make of it (noise at full quality has no end-of-block codes to fall back into
+        # step at, so nearly all of these fail -- in both)
+        try:
+            want = po.decode(v, w, h, quality)
+        except RuntimeError:
+            want = None
+        try:
+            got = ctx.decode_host(v, w, h, lum, chrom)
+        except jea.JeaError:
+            got = None
+        assert (want is None) == (got is None)
+        if want is not None:
+            assert np.array_equal(got, want)
+    # random byte strings rich in 0xFF and 0x00, of lengths around the kernels' piece and chunk sizes
+    rng = np.random.RandomState(5)
+    for n in (2, 3, 15, 16, 17, 31, 33, 4095, 4096, 4097, 4111, 8192, 70001):
+        for _ in range(3):
+            raw = rng.choice(np.array([0xFF, 0xFF, 0x00, 0x00, 0x01], np.uint8), n).tobytes()
+            buf = np.frombuffer(raw, np.uint8).copy()
+            m = po.LIB.jo_remove_stuffing(buf.ctypes.data, 0, buf.size)
+            assert ctx.remove_stuffing(raw) == buf[:m].tobytes(), n
+
+
 def test_decode_with_the_files_own_header(ctx, po, jea):
     """jea_read_header + jea_decode_host decode a file without being told size or quality."""
     for quality, (w, h) in [(60, (200, 120)), (92, (64, 48))]:

@@ -42,12 +42,27 @@ def test_baseline_encoder_cpp_on_gpu(tmp_path):
     assert any(ln.startswith("blockwise_encode_matches 1") for ln in lines), r.stdout
     assert "blockwise_decode_matches 1" in lines
     assert "blockwise_decode_eoi_missing" not in r.stdout
-    # injected component without a GPU implementation: reference error convention, nothing produced
     # the reference's other mapper, injected: the GPU path equals the per-block loop
     assert any(ln.startswith("passthrough_encode_matches 1") for ln in lines), r.stdout
     assert "passthrough_decode_matches 1" in lines
-    assert "[Error]: The injected cosine transformer has no GPU implementation" in lines
-    assert "no_device_path_size 0" in lines
+    # a user's colour mapper: per-block fallback through the user's virtuals, equal to the library's mapper on the
+    # fused path and to the oracle's restatement of that mapper (whose pass-through leg nothing of the reference pins)
+    import pyoracle as po
+    user = next(ln.split() for ln in lines if ln.startswith("user_mapper_encode_matches"))
+    assert user[1] == "1" and int(user[3]) == 6 * 4 and user[5] == "0", r.stdout
+    rgb = po.gen_image(45, 30, 1, 3)
+    po.set_mapper(1)
+    try:
+        want = po.encode(rgb, 65)
+        want_rgb = po.decode(want, 45, 30, 65)
+    finally:
+        po.set_mapper(0)
+    assert user[7] == po.fnv(want)
+    dec = next(ln.split() for ln in lines if ln.startswith("user_mapper_decode_matches"))
+    assert dec[1] == "1" and dec[3] == po.fnv(want_rgb.reshape(-1))
+    # a user's entropy coder that overrides the protected final-encoding step of the reference's interface
+    assert "user_entropy_coder encode_matches 1 decode_matches 1 encoded %d decoded %d" % (3 * 4 * 3, 3 * 4 * 3) in lines, r.stdout
+    assert "[Error]: Invalid runtime encoding encountered." in lines and "bad_entries_done" in lines
     assert "[Error]: Failed to find SOI marker" in lines
     assert "broken_header_pixels 0" in lines
     assert "bmp_round_trip 1" in lines

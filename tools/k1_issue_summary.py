@@ -33,7 +33,7 @@ def counters(directory, kernel, grid=None):
                 acc[int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if not acc:
         return None, {}
-    g = grid if grid in acc else (max(acc, key=lambda k: len(next(iter(acc[k].values())))) if grid is None else max(acc))
+    g = grid if grid in acc else max(acc)   # the grid asked for, else the largest launch
     return g, {c: sum(v) / len(v) for c, v in acc[g].items()}
 
 

@@ -16,7 +16,8 @@ def main():
         for r in csv.DictReader(open(f)):
             m = re.search(r"(\w+_kernel)(<[^>]*>)?", r["Kernel_Name"])
             name = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:48]
-            acc[(name, int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            acc[(name, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     out = {"command": sys.argv[1], "unit": "ns", "kernels": []}
     for (name, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         out["kernels"].append({"kernel": name, "grid": grid, "calls": len(v), "mean": round(sum(v) / len(v), 1), "min": min(v),
