@@ -31,6 +31,8 @@ def counters(directory, kernel, grid=None):
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"]:
                 acc[int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                    acc[int(r["Grid_Size"])]["_duration_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     if not acc:
         return None, {}
     g = grid if grid in acc else max(acc)   # the grid asked for, else the largest launch
@@ -112,6 +114,9 @@ def main():
     if cm:
         cycles = cm["GRBM_GUI_ACTIVE"] / 8
         out["counters_many_image_launch"] = {"grid": gm, **{k: round(v, 1) for k, v in sorted(cm.items())}}
+        if cm.get("_duration_ns"):
+            # GRBM_GUI_ACTIVE / 8 / duration: within a few per cent of the in-kernel clock on dispatches of a millisecond and more
+            out["shader_clock_mhz"] = round(cycles / cm["_duration_ns"] * 1e3)
         busy = cm["SQ_INSTS_VALU"] / 1024 / cycles
         out["many_image_launch"] = {
             "images": gm // 388800, "gui_active_cycles_per_xcd": round(cycles),
