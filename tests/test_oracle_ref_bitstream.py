@@ -102,3 +102,54 @@ def test_stuffing_matches_reference(ref, po):
     buf = np.frombuffer(want + b"\xff\xd9", np.uint8).copy()
     n = po.LIB.jo_remove_stuffing(buf.ctypes.data, 8, buf.size)
     assert buf[:n].tobytes() == bytes(data) + b"\xff\xd9"
+
+
+def _reference_walk_stays_inside(raw, start):
+    """removeStuffedBytes compares its iterator with end() - 2 by `!=`: a 0xFF three bytes before the end that is
+    not followed by 0x00 carries it past that point and off the vector.  True when the walk ends on end() - 2."""
+    data, i = list(raw), start
+    while i != len(data) - 2:
+        if i > len(data) - 2:
+            return False
+        if data[i] == 0xFF:
+            i += 1
+            if i >= len(data):
+                return False
+            if data[i] == 0x00:
+                del data[i]
+                continue
+        i += 1
+    return True
+
+
+def test_unstuffing_of_ff_runs_matches_reference(ref, po):
+    """removeStuffedBytes (bit_stream.cpp:136-147) on byte strings no encoder produces: runs of 0xFF before a
+    0x00, zeros after zeros.  After a 0xFF that no 0x00 follows the reference steps over the following byte as
+    well, so in FF FF 00 the zero stays and in FF FF FF 00 it goes; the oracle's restatement must leave the same
+    bytes, from every starting offset.  Strings on which the reference walks off its vector are left out."""
+    rng = np.random.RandomState(23)
+    tail = bytes([0x05, 0xFF, 0xD9])
+    cases = [bytes([0xFF, 0xFF, 0x00, 0x11, 0x22]) + tail, bytes([0xFF, 0xFF, 0xFF, 0x00, 0x11, 0x22]) + tail,
+             bytes([0x01, 0xFF, 0x00, 0x00, 0xFF, 0x00]) + tail, bytes([0xFF, 0x00] * 4) + tail,
+             bytes([0xFF] * 40 + [0x00]) + tail, bytes([0xFF] * 41 + [0x00]) + tail]
+    for n in (2, 3, 4, 5, 8, 17, 64, 257, 1000):
+        for _ in range(12):
+            body = rng.choice(np.array([0xFF, 0xFF, 0x00, 0x00, 0x01], np.uint8), n).tobytes()
+            cases.append(body + tail)
+            cases.append(body + b"\xff\xd9")
+    compared = 0
+    for raw in cases:
+        for start in (0, 1, 3):
+            if start > len(raw) - 2 or not _reference_walk_stays_inside(raw, start):
+                continue
+            s = ref.refbs_new()
+            for b in raw:
+                ref.refbs_push_bits(s, int(b), 8)
+            ref.refbs_unstuff(s, start)
+            want = _ref_bytes(ref, s)
+            ref.refbs_delete(s)
+            buf = np.frombuffer(raw, np.uint8).copy()
+            n = po.LIB.jo_remove_stuffing(buf.ctypes.data, start, buf.size)
+            assert buf[:n].tobytes() == want, (raw.hex(), start)
+            compared += 1
+    assert compared > 400
