@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: r02_tests.sh [pytest args]; the GPU suite (or the tests named), output to gpurun_out/tests.log
+# usage: gpu_tests.sh [pytest args]; the GPU suite (or the tests named), output to gpurun_out/tests.log
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
