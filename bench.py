@@ -539,9 +539,11 @@ def config_c5(job):
                               "jea_decode_batch the kernel reads block records and only the chunks that exist",
                 "other_kernels": {
                     "decode_write_kernel(+scan)": {"us": round(ph[2] * 1e3, 1), "algorithmic_bytes": int(stream_bytes + 6 * px),
-                                                   "frac": round((stream_bytes + 6 * px) / (ph[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                   "note": "stream bytes read + 6 B/px of coefficients written (standard layout); "
-                                                           "bound by the latency of the serial walks, not by memory"},
+                                                   "standard_layout_equivalent_GBps": round((stream_bytes + 6 * px) / (ph[2] * 1e-3) / 1e9, 1),
+                                                   "note": "stream bytes read + 6 B/px of coefficients written is the standard layout's figure; "
+                                                           "inside jea_decode_batch the pass stores one 4-byte record per block plus the chunks "
+                                                           "that hold a non-zero AC coefficient, far fewer bytes, so the equivalent rate may exceed "
+                                                           "the HBM peak; bound by the latency of the serial walks, not by memory"},
                     "decode_sync_kernel x2": {"us": round(ph[1] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes)},
                     "unstuff kernels": {"us": round(ph[0] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes)}}}
     cpu = None
