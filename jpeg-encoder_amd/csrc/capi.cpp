@@ -264,9 +264,29 @@ bool build_decode_table(const uint8_t bits[16], const uint8_t* vals, DecodeTable
     return true;
 }
 
-// The parallel decoder's view of the same code (kernels.h, StepTableT).
+// Canonical code of `sym` in a table given as Annex C counts and values; false when the table lacks it.
+bool find_code(const uint8_t bits[16], const uint8_t* vals, uint32_t sym, uint32_t& code_out, uint32_t& len_out) {
+    uint32_t code = 0;
+    int k = 0;
+    for (uint32_t l = 1; l <= 16; ++l) {
+        for (int i = 0; i < bits[l - 1]; ++i, ++k) {
+            if (vals[k] == sym) {
+                code_out = code;
+                len_out = l;
+                return true;
+            }
+            ++code;
+        }
+        code <<= 1;
+    }
+    return false;
+}
+
+// The parallel decoder's view of the same code (kernels.h, StepTableT).  eob_code / eob_len: the end-of-block
+// code of the AC table of the same class, for the combined entries.
 template <class Table>
-bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, Table& t) {
+bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, uint32_t eob_code, uint32_t eob_len,
+                      Table& t) {
     constexpr uint32_t F = Table::kFastBits, kSub = 1u << (16 - F);   // sub-table: one entry per 16-bit prefix
     const uint32_t bad = kStepBad | 1u;   // skip one bit, keep going
     for (uint32_t& e : t.fast) e = bad;
@@ -283,8 +303,8 @@ bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, T
             const bool valid = is_dc ? sym <= 11u : (ss <= 10u && (ss != 0u || sym == 0x00u || sym == 0xF0u));
             uint32_t entry = bad;
             if (valid) {
-                const uint32_t run_code = (!is_dc && sym == 0x00u) ? kStepRunEob : run;
-                entry = (l + ss) | (run_code << 8) | (l << 16) | (((32u - ss) & 31u) << 24);
+                entry = (l + ss) | (run << 8) | (l << 16) | (((32u - ss) & 31u) << 24);
+                if (!is_dc && sym == 0x00u) entry |= kStepEndsBlock;
                 if (ss) entry |= kStepHasAmp | (is_dc ? kStepDcAdd : 0u);
             }
             if (l <= F) {
@@ -303,6 +323,15 @@ bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, T
         code <<= 1;
     }
     if (((1u << F) - first_bucket) * kSub > (uint32_t)Table::kSlowEntries) return false;
+    // combined entries: the symbol, its amplitude bits and the end-of-block code all inside the index bits
+    if (eob_len >= 1 && eob_len <= 7) {
+        for (uint32_t j = 0; j < first_bucket; ++j) {
+            const uint32_t e = t.fast[j], used = e & 0xffu;
+            if ((e & (kStepBad | kStepEndsBlock)) || !(is_dc || (e & kStepHasAmp)) || used + eob_len > F) continue;
+            if (((j >> (F - used - eob_len)) & ((1u << eob_len) - 1u)) != eob_code) continue;
+            t.fast[j] = (e + eob_len) | kStepEndsBlock | (eob_len << kStepEobLenShift);
+        }
+    }
     for (uint32_t j = first_bucket; j < (1u << F); ++j) {
         const uint32_t offset = (uint32_t)offsetof(Table, slow) + (j - first_bucket) * kSub * 4u;
         t.fast[j] = ((kSub - 1u) << 8) | (offset << 16);
@@ -465,8 +494,12 @@ int jea_create(int device_id, jea_ctx** out_ctx) {
         return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: Huffman tables do not fit the decode tables");
     }
     StepTables st;
-    if (!build_step_table(kDcLumBits, kDcVals, true, st.cls[0].dc) || !build_step_table(kAcLumBits, kAcLumVals, false, st.cls[0].ac) ||
-        !build_step_table(kDcChrBits, kDcVals, true, st.cls[1].dc) || !build_step_table(kAcChrBits, kAcChrVals, false, st.cls[1].ac)) {
+    uint32_t eob_code[2] = {0, 0}, eob_len[2] = {0, 0};
+    if (!find_code(kAcLumBits, kAcLumVals, 0x00u, eob_code[0], eob_len[0]) || !find_code(kAcChrBits, kAcChrVals, 0x00u, eob_code[1], eob_len[1]) ||
+        !build_step_table(kDcLumBits, kDcVals, true, eob_code[0], eob_len[0], st.cls[0].dc) ||
+        !build_step_table(kAcLumBits, kAcLumVals, false, eob_code[0], eob_len[0], st.cls[0].ac) ||
+        !build_step_table(kDcChrBits, kDcVals, true, eob_code[1], eob_len[1], st.cls[1].dc) ||
+        !build_step_table(kAcChrBits, kAcChrVals, false, eob_code[1], eob_len[1], st.cls[1].ac)) {
         jea_destroy(ctx);
         return fail(nullptr, JEA_ERR_INVALID_ARG, "jea_create: Huffman tables do not fit the decode tables");
     }
@@ -1117,7 +1150,7 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
 // kernels made of a file with a bad header is bounded and thrown away.
 static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_t* h_offsets, const uint64_t* h_sizes,
                               size_t n_images, uint64_t skip, size_t mcus, int16_t* d_coefs, const char* what,
-                              uint32_t* d_block_records = nullptr, const std::function<void()>& follow_up = nullptr) {
+                              uint32_t* d_block_records = nullptr, const DecodeFollowUp& follow_up = nullptr) {
     int rc;
     const bool with_headers = skip == JEA_HEADER_BYTES;
     const size_t seg_bytes = 3 * n_images * sizeof(uint64_t);   // offsets | sizes | unstuffed bases
@@ -1160,9 +1193,10 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     if ((rc = ensure(ctx, ctx->ctx_vals, kContextSlots * sizeof(uint32_t)))) return rc;
     // the pinned block is this context's and the call ends with a wait: the copy may run behind the host;
     // a few images' worth goes as kernel arguments instead, which is quicker than the copy engine
+    DecodePrologue prologue;
     if (3 * n_images <= kSeedWords) {
-        launch_seed_words(ctx->stream, (uint64_t*)ctx->seg_offsets.ptr, seg, (uint32_t)(3 * n_images));
-        JEA_HIP(ctx, hipGetLastError());
+        prologue.h_words = seg;
+        prologue.n_words = (uint32_t)(3 * n_images);
     } else {
         JEA_HIP(ctx, hipMemcpyAsync(ctx->seg_offsets.ptr, seg, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
@@ -1176,14 +1210,19 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
         return JEA_OK;
     };
     if (with_headers) {
-        // one gather for the whole batch, straight into the pinned block: a copy to the host in this place
+        // gathered by the decoder's first kernel straight into the pinned block: a copy to the host in this place
         // would hold up the decoder's kernels behind it for the latency of the copy engine (about 20 us)
-        launch_gather_headers(ctx->stream, d_data, d_seg, n_images, JEA_HEADER_BYTES, hdr);
-        JEA_HIP(ctx, hipGetLastError());
+        prologue.headers_out = hdr;
+        prologue.header_bytes = JEA_HEADER_BYTES;
     }
     if (too_short) {   // nothing to decode: only the order of the two messages matters
-        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (with_headers && (rc = headers_ok())) return rc;
+        if (with_headers) {
+            for (size_t i = 0; i < n_images; ++i)
+                JEA_HIP(ctx, hipMemcpyAsync(hdr + i * JEA_HEADER_BYTES, d_data + h_offsets[i], JEA_HEADER_BYTES,
+                                            hipMemcpyDeviceToHost, ctx->stream));
+            JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if ((rc = headers_ok())) return rc;
+        }
         return fail(ctx, JEA_ERR_NO_EOI, "Failed to find EOI marker");
     }
     DecodeScratch sc;
@@ -1212,7 +1251,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
         sc.marks = ctx->marks + 1;
     }
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
-                                       ctx->d_status, follow_up, report));
+                                       ctx->d_status, follow_up, report, prologue));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->profiling) ctx->n_marks = 5;   // unstuffing | synchronisation rounds | scan and write pass | follow-up
     if (with_headers && (rc = headers_ok())) return rc;
@@ -1236,8 +1275,9 @@ int jea_remove_stuffing(jea_ctx* ctx, const uint8_t* d_scan, size_t len, uint8_t
     if ((rc = ensure(ctx, ctx->img_drops, sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->round_flags, 4 * sizeof(uint32_t)))) return rc;
     const uint64_t seg[3] = {0, (uint64_t)len, 0};   // offset | size | base of the unstuffed copy
-    launch_seed_words(ctx->stream, (uint64_t*)ctx->seg_offsets.ptr, seg, 3);
-    JEA_HIP(ctx, hipGetLastError());
+    DecodePrologue prologue;
+    prologue.h_words = seg;
+    prologue.n_words = 3;
     const uint64_t* d_seg = (const uint64_t*)ctx->seg_offsets.ptr;
     DecodeScratch sc{};
     sc.ubase = d_seg + 2;
@@ -1246,7 +1286,7 @@ int jea_remove_stuffing(jea_ctx* ctx, const uint8_t* d_scan, size_t len, uint8_t
     sc.chunk_base = (uint64_t*)ctx->chunk_base.ptr;
     sc.img_drops = (uint64_t*)ctx->img_drops.ptr;
     sc.changed = (uint32_t*)ctx->round_flags.ptr;
-    JEA_HIP(ctx, launch_unstuff(ctx->stream, d_scan, d_seg, d_seg + 1, plan, sc, ctx->d_status));
+    JEA_HIP(ctx, launch_unstuff(ctx->stream, d_scan, d_seg, d_seg + 1, plan, sc, ctx->d_status, prologue));
     uint64_t drops = 0;
     JEA_HIP(ctx, hipMemcpyAsync(&drops, sc.img_drops, sizeof(drops), hipMemcpyDeviceToHost, ctx->stream));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1285,9 +1325,10 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     // The inverse transform is enqueued right behind the write pass, before anything is known about the
     // stream: a decode waits for the GPU once.  So when an error is reported, d_rgb holds garbage.
     const QuantTables qt = to_float_tables(lum_q, chr_q);
-    auto inverse = [&]() {
+    auto inverse = [&](const DecodeReportRelay& relay) {
         launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height, qt, d_rgb,
-                            (const uint32_t*)ctx->masks.ptr, ctx->mode);
+                            (const uint32_t*)ctx->masks.ptr, ctx->mode, relay);
+        return true;
     };
     return run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,
                               (int16_t*)ctx->coefs.ptr, "jea_decode_batch", (uint32_t*)ctx->masks.ptr, inverse);

@@ -128,24 +128,43 @@ __device__ __forceinline__ uint32_t drop_mask16(const uint8_t* __restrict__ file
     return mask;
 }
 
+struct SegmentWords {
+    uint64_t v[kSeedWords];
+};
+
+// The decoder's first kernel.  Besides counting it does the small jobs that would otherwise be launches of
+// their own at the head of the chain, where the GPU waits for the host: it clears what the later kernels
+// report into; with n_words != 0 the scan ranges arrive as kernel arguments (offsets | sizes | unstuffed
+// bases, n images each) and are left in d_words for the kernels that follow; with headers_out given it
+// copies the header_bytes bytes in front of every scan there (pinned host memory: the host validates all
+// headers after the one wait of the call, and no copy sits in the stream between the decoder's kernels).
 __global__ __launch_bounds__(kThreads) void unstuff_count_kernel(const uint8_t* __restrict__ scan,
                                                                  const uint64_t* __restrict__ offsets,
                                                                  const uint64_t* __restrict__ sizes,
                                                                  uint32_t n_chunks,
                                                                  uint32_t* __restrict__ chunk_drops,
                                                                  uint32_t* __restrict__ round_flags,
-                                                                 int32_t* __restrict__ status) {
+                                                                 int32_t* __restrict__ status,
+                                                                 SegmentWords words, uint32_t n_words,
+                                                                 uint64_t* __restrict__ d_words,
+                                                                 uint8_t* __restrict__ headers_out,
+                                                                 uint32_t header_bytes) {
     __shared__ uint32_t wsum[4];
     const uint32_t chunk = blockIdx.x, img = blockIdx.y;
-    // the decoder's first kernel also clears what the later ones report into
     if (chunk == 0 && img == 0 && threadIdx.x < 4) round_flags[threadIdx.x] = 0;
     if (chunk == 0 && img == 0 && threadIdx.x == 4) *status = 0;
-    const uint64_t len = sizes[img];
+    if (chunk == 0 && img == 0 && threadIdx.x < n_words) d_words[threadIdx.x] = words.v[threadIdx.x];
+    const uint64_t offset = n_words ? words.v[img] : offsets[img];
+    const uint64_t len = n_words ? words.v[gridDim.y + img] : sizes[img];
+    if (headers_out != nullptr && chunk == 0) {
+        const uint8_t* src = scan + offset - header_bytes;
+        for (uint32_t i = threadIdx.x; i < header_bytes; i += kThreads) headers_out[(size_t)img * header_bytes + i] = src[i];
+    }
     const uint64_t j0 = (uint64_t)chunk * kChunkBytes + 16u * threadIdx.x;
     uint32_t n = 0;
     if (j0 < len) {
         uint8_t bytes[16];
-        n = __popc(drop_mask16(scan + offsets[img], len, len >= 2 ? len - 2 : 0, j0, bytes));
+        n = __popc(drop_mask16(scan + offset, len, len >= 2 ? len - 2 : 0, j0, bytes));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
@@ -327,11 +346,12 @@ __device__ __forceinline__ void load_tables(StepTables& t, const StepTables* __r
 
 constexpr uint32_t kClassBytes = sizeof(StepClass);    // luminance tables first, then chrominance
 constexpr uint32_t kAcBytes = sizeof(StepTableDc);     // DC table first, then AC
-constexpr uint32_t kDcShift = 32 - StepTableDc::kFastBits, kAcShift = 32 - StepTableAc::kFastBits;
+static_assert(StepTableDc::kFastBits == StepTableAc::kFastBits, "one shift for both tables");
+constexpr uint32_t kStepShift = 32 - StepTableAc::kFastBits;
 
-// `tab`: the table to use (in LDS), v: the next 32 stream bits, shift: 32 - the table's fast bits.
-__device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v, uint32_t shift) {
-    uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> shift) << 2));
+// `tab`: the table to use (in LDS), v: the next 32 stream bits.
+__device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v) {
+    uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> kStepShift) << 2));
     if ((e & 0xffu) == 0) e = *reinterpret_cast<const uint32_t*>(tab + (e >> 16) + (((v >> 16) & ((e >> 8) & 0xffu)) << 2));
     return e;
 }
@@ -370,19 +390,19 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
     const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
     uint32_t o0 = class_offset(lum_mask, c0), o1 = class_offset(lum_mask, c1), o2 = class_offset(lum_mask, c2);
     uint32_t k = z ? kAcBytes : 0u;     // DC table at the start of a block, AC table inside
-    uint32_t shift = z ? kAcShift : kDcShift;
     int nb = 0, a0 = 0, a1 = 0, a2 = 0;
     BitWindow<GroupWords<W>> win(gw, p);
     while (p < end) {
         const uint32_t v = win.peek(p);
-        const uint32_t e = step_lookup(tb + o0 + k, v, shift);
+        const uint32_t e = step_lookup(tb + o0 + k, v);
         p += e & 0xffu;
+        // AC positions consumed including this entry, plus 128 when the entry ends the block
+        const uint32_t processed = z + ((e >> 8) & 0xffu);
+        if (__builtin_expect(processed == 128u + 63u, 0)) p -= (e >> kStepEobLenShift) & 7u;   // see kernels.h: combined entries
         win.follow(p);
-        const uint32_t processed = z + ((e >> 8) & 0xffu);   // AC positions consumed including this entry
         const bool done = processed >= 63u;                  // end of block, or the block is full
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
-        shift = done ? kDcShift : kAcShift;
         a0 += ((int32_t)e < 0) ? step_amplitude(v, e) : 0;   // kStepDcAdd
         nb += done ? 1 : 0;
         const uint32_t o = o0;
@@ -507,7 +527,6 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     int l1 = c1 == 0 ? wt.last0 : (c1 == 1 ? wt.last1 : wt.last2);
     int l2 = c2 == 0 ? wt.last0 : (c2 == 1 ? wt.last1 : wt.last2);
     uint32_t k = z ? kAcBytes : 0u;
-    uint32_t shift = z ? kAcShift : kDcShift;
     uint32_t block = wt.block;
     // Where chunk 0 of the current block and of the two after it go; rotated like the rest, so that no
     // block has to derive its place from its index.
@@ -539,26 +558,28 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
             bw.begin(d0, stride, record);
         }
         const uint32_t v = win.peek(p);
-        const uint32_t e = step_lookup(tb + o0 + k, v, shift);
+        const uint32_t e = step_lookup(tb + o0 + k, v);
         const bool is_dc = k == 0;
         p += e & 0xffu;
-        win.follow(p);
-        // AC positions consumed including this entry; the end-of-block symbol counts as kStepRunEob,
-        // so values 64..127 can only come from an entry that does not fit: the serial decoder's error
+        // AC positions consumed including this entry, plus 128 when the entry ends the block (the end-of-block
+        // symbol, or a symbol with that code behind it).  Bit 6 -- 64..127 and 192..255 -- can only come from
+        // an entry that reaches past position 63: the serial decoder's error
         const uint32_t processed = z + ((e >> 8) & 0xffu);
+        if (__builtin_expect(processed == 128u + 63u, 0)) p -= (e >> kStepEobLenShift) & 7u;   // see kernels.h: combined entries
+        win.follow(p);
         const bool done = processed >= 63u;
+        const uint32_t position = processed & 0x7fu;
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
-        shift = done ? kDcShift : kAcShift;
         if (owning) {
             const int amp = (e & kStepHasAmp) ? step_amplitude(v, e) : 0;
             trouble |= processed | (e & kStepBad);
             if (is_dc) {
                 l0 = (int)(int16_t)(l0 + amp);   // entropy_encoder.cpp:125-126: the DC chain runs in int16
                 bw.put_dc(l0);
-            } else if (!done && (e & kStepHasAmp)) {
-                // an entry that completes the block is the last one and is dropped (entropy_encoder.cpp:129)
-                bw.put(processed, amp);
+            } else if (position < 63u && (e & kStepHasAmp)) {
+                // an entry that fills position 63 is the block's last one and is dropped (entropy_encoder.cpp:129)
+                bw.put(position, amp);
             }
         }
         if (done) {
@@ -852,7 +873,14 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
     if (threadIdx.x == 0 && (uint32_t)carry_s.nb < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
 }
 
-template <uint32_t W, bool kPlanar>
+// kFold (streams of up to kFoldGroups workgroups): there is no scan launch before this kernel.  Every workgroup
+// adds up the sums of the workgroups before it, checks what scan_groups_kernel checks for its own part -- that
+// its first sub-sequence was decoded from the end state of the sub-sequence before it and that it did not run out
+// of repair steps (else *unsettled is set) -- and the workgroup with the end of the stream sees whether the
+// stream held enough blocks.
+constexpr uint32_t kFoldGroups = 1024;
+
+template <uint32_t W, bool kPlanar, bool kFold>
 __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* __restrict__ ustream,
                                                                 const uint64_t* __restrict__ ubase,
                                                                 const uint64_t* __restrict__ sizes,
@@ -864,7 +892,11 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const int4* __restrict__ grp_base,
                                                                 int16_t* __restrict__ coefs,
                                                                 uint32_t* __restrict__ records, uint32_t lum_mask,
-                                                                int32_t* __restrict__ status) {
+                                                                int32_t* __restrict__ status,
+                                                                const int4* __restrict__ grp_sum,
+                                                                const uint32_t* __restrict__ sub_end,
+                                                                const uint32_t* __restrict__ grp_pending,
+                                                                uint32_t* __restrict__ unsettled) {
     constexpr uint32_t kSubBits = 32 * W;
     __shared__ GroupWords<W, kWriteTail> gw;
     __shared__ StepTables t;
@@ -874,8 +906,42 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const uint64_t ulen = sizes[img] - img_drops[img];
     const uint64_t total_bits = 8 * ulen;
-    if ((uint64_t)group * kOwned * kSubBits >= total_bits) return;
-    const int4 gb = grp_base[(size_t)img * n_groups + group];
+    if ((uint64_t)group * kOwned * kSubBits >= total_bits) {
+        if (kFold && group == 0 && tid == 0 && total_blocks != 0) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);   // an empty stream
+        return;
+    }
+    int4 gb;
+    if (kFold) {
+        Sums before{0, 0, 0, 0};
+        for (uint32_t g = tid; g < group; g += kThreads) {
+            const int4 v = grp_sum[(size_t)img * n_groups + g];
+            before = before + Sums{v.x, v.y, v.z, v.w};
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            before = before + Sums{__shfl_xor(before.nb, d), __shfl_xor(before.dc0, d), __shfl_xor(before.dc1, d),
+                                   __shfl_xor(before.dc2, d)};
+        if ((tid & 63) == 0) lds4[tid >> 6] = before;
+        __syncthreads();
+        before = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+        __syncthreads();
+        gb = make_int4(before.nb, before.dc0, before.dc1, before.dc2);
+        if (tid == 0) {
+            const size_t first = ((size_t)img * n_groups + group) * kOwned;
+            if (unsettled != nullptr) {
+                const uint32_t entry = group > 0 ? sub_end[first - 1] : 0u;   // the stream starts in state 0
+                if (entry != sub_used[first] || grp_pending[(size_t)img * n_groups + group] != 0) atomicOr(unsettled, 1u);
+            }
+            // the workgroup that holds the end of the stream: fewer blocks than the picture needs is a stream
+            // error (the serial decoder would run off the end of the file)
+            if ((uint64_t)(group + 1) * kOwned * kSubBits >= total_bits) {
+                const int4 own = grp_sum[(size_t)img * n_groups + group];
+                if ((uint32_t)(before.nb + own.x) < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
+            }
+        }
+    } else {
+        gb = grp_base[(size_t)img * n_groups + group];
+    }
     if ((uint32_t)gb.x >= total_blocks) return;   // the picture is complete before this group
     // slot tid holds the group's tid-th sub-sequence; the last kWarm threads have none
     const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + tid;
@@ -958,34 +1024,6 @@ __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t* __res
 
 }  // namespace
 
-namespace {
-__global__ void gather_headers_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ scan_offsets,
-                                      uint32_t header_bytes, uint8_t* __restrict__ out) {
-    const uint8_t* src = data + scan_offsets[blockIdx.x] - header_bytes;
-    for (uint32_t i = threadIdx.x; i < header_bytes; i += blockDim.x) out[(size_t)blockIdx.x * header_bytes + i] = src[i];
-}
-}  // namespace
-
-namespace {
-struct SegmentWords {
-    uint64_t v[kSeedWords];
-};
-__global__ void seed_words_kernel(uint64_t* __restrict__ dst, SegmentWords words, uint32_t count) {
-    if (threadIdx.x < count) dst[threadIdx.x] = words.v[threadIdx.x];
-}
-}  // namespace
-
-void launch_seed_words(hipStream_t s, uint64_t* d_dst, const uint64_t* h_words, uint32_t count) {
-    SegmentWords w{};
-    for (uint32_t i = 0; i < count && i < kSeedWords; ++i) w.v[i] = h_words[i];
-    seed_words_kernel<<<1, kSeedWords, 0, s>>>(d_dst, w, count);
-}
-
-void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
-                           uint32_t header_bytes, uint8_t* d_out) {
-    gather_headers_kernel<<<(unsigned)n_images, 256, 0, s>>>(d_data, d_scan_offsets, header_bytes, d_out);
-}
-
 DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image) {
     DecodePlan p;
     p.n_images = (uint32_t)n_images;
@@ -1029,20 +1067,24 @@ struct DecodeRun {
                                                          sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
                                                          sc.first_bad, sc.mode.lum_mask, flag);
     }
+    template <bool kPlanar, bool kFold>
+    void write(uint32_t* check) const {
+        decode_write_kernel<W, kPlanar, kFold><<<grid(), kThreads, 0, s>>>(
+            sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, p.total_blocks, d_tables, sc.sub_used, sc.sub_info,
+            sc.grp_base, d_coefs, kPlanar ? sc.out_records : nullptr, sc.mode.lum_mask, d_status, sc.grp_sum, sc.sub_end,
+            sc.grp_pending, check);
+    }
     void scan_and_write(uint32_t* check = nullptr) const {
-        scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
-                                                           d_status, d_sizes, sc.img_drops, 32 * W, sc.sub_end,
-                                                           sc.sub_used, sc.grp_pending, check);
-        if (sc.out_records != nullptr)
-            decode_write_kernel<W, true><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
-                                                                    p.n_groups, p.total_blocks, d_tables, sc.sub_used,
-                                                                    sc.sub_info, sc.grp_base, d_coefs, sc.out_records,
-                                                                    sc.mode.lum_mask, d_status);
-        else
-            decode_write_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops,
-                                                                     p.n_groups, p.total_blocks, d_tables, sc.sub_used,
-                                                                     sc.sub_info, sc.grp_base, d_coefs, nullptr,
-                                                                     sc.mode.lum_mask, d_status);
+        const bool fold = p.n_groups <= kFoldGroups;
+        if (!fold)
+            scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
+                                                               d_status, d_sizes, sc.img_drops, 32 * W, sc.sub_end,
+                                                               sc.sub_used, sc.grp_pending, check);
+        const bool planar = sc.out_records != nullptr;
+        if (planar && fold) write<true, true>(check);
+        else if (planar) write<true, false>(check);
+        else if (fold) write<false, true>(check);
+        else write<false, false>(check);
     }
 
     // Two rounds up front: the first decodes everything, the second repairs the starts of the
@@ -1050,15 +1092,15 @@ struct DecodeRun {
     // which is the proof of the fixed point.  The write pass and whatever consumes the coefficients
     // follow at once; the outcome of the check is reported together with the status, so the usual
     // decode never waits for the GPU in the middle.
-    hipError_t first_pass(const std::function<void()>& follow_up, DecodeReport* report) const {
+    hipError_t first_pass(const DecodeFollowUp& follow_up, DecodeReport* report) const {
         sync_round(1, sc.changed + 0, false);
         sync_round(0, sc.changed + 1, false);
         if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[1], s);
         scan_and_write(sc.changed + 2);
         if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[2], s);
-        if (follow_up) follow_up();
+        const bool relayed = follow_up && follow_up(DecodeReportRelay{sc.changed + 2, d_status, report});
         if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[3], s);
-        report_kernel<<<1, 1, 0, s>>>(sc.changed + 2, d_status, report);
+        if (!relayed) report_kernel<<<1, 1, 0, s>>>(sc.changed + 2, d_status, report);
         return hipGetLastError();
     }
 
@@ -1067,7 +1109,7 @@ struct DecodeRun {
     // proven start states are offered as guesses wherever the same 512 stream bits come before
     // (periodic streams of flat or patterned pictures then settle in a handful of rounds).  What the
     // write pass produced from the unfinished states (bounded, but meaningless) is produced again.
-    hipError_t repair(const std::function<void()>& follow_up, DecodeReport* report) const {
+    hipError_t repair(const DecodeFollowUp& follow_up, DecodeReport* report) const {
         hipError_t e;
         const uint64_t max_rounds = (uint64_t)p.subs_per_image / kMaxLocalIterations + p.n_groups + 8;
         if ((e = hipMemsetAsync(sc.ctx_keys, 0, (size_t)sc.ctx_slots * sizeof(unsigned long long), s)) != hipSuccess) return e;
@@ -1092,8 +1134,8 @@ struct DecodeRun {
         }
         if ((e = hipMemsetAsync(d_status, 0, sizeof(int32_t), s)) != hipSuccess) return e;
         scan_and_write();
-        if (follow_up) follow_up();
-        report_kernel<<<1, 1, 0, s>>>(sc.changed + 3, d_status, report);
+        const bool relayed = follow_up && follow_up(DecodeReportRelay{sc.changed + 3, d_status, report});
+        if (!relayed) report_kernel<<<1, 1, 0, s>>>(sc.changed + 3, d_status, report);
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         return hipGetLastError();
     }
@@ -1102,10 +1144,14 @@ struct DecodeRun {
 
 // bit_stream.cpp:136-147 for every stream of the job: count, (scan,) compact.  Clears *d_status and the round flags.
 hipError_t launch_unstuff(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
-                          const DecodePlan& p, const DecodeScratch& sc, int32_t* d_status) {
+                          const DecodePlan& p, const DecodeScratch& sc, int32_t* d_status, const DecodePrologue& pro) {
     const dim3 cgrid(p.n_chunks, p.n_images);
+    SegmentWords words{};
+    if (pro.n_words > kSeedWords || (pro.n_words != 0 && pro.n_words != 3 * p.n_images)) return hipErrorInvalidValue;
+    for (uint32_t i = 0; i < pro.n_words; ++i) words.v[i] = pro.h_words[i];
     unstuff_count_kernel<<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops, sc.changed,
-                                                    d_status);
+                                                    d_status, words, pro.n_words, const_cast<uint64_t*>(d_offsets),
+                                                    pro.headers_out, pro.header_bytes);
     if (p.n_chunks <= kFoldChunks) {
         unstuff_compact_kernel<true><<<cgrid, kThreads, 0, s>>>(d_scan, d_offsets, d_sizes, p.n_chunks, sc.chunk_drops,
                                                                 nullptr, sc.img_drops, sc.ubase, sc.ustream);
@@ -1120,9 +1166,9 @@ hipError_t launch_unstuff(hipStream_t s, const uint8_t* d_scan, const uint64_t* 
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
-                                 const std::function<void()>& follow_up, DecodeReport* report) {
+                                 const DecodeFollowUp& follow_up, DecodeReport* report, const DecodePrologue& pro) {
     hipError_t e;
-    if ((e = launch_unstuff(s, d_scan, d_offsets, d_sizes, p, sc, d_status)) != hipSuccess) return e;
+    if ((e = launch_unstuff(s, d_scan, d_offsets, d_sizes, p, sc, d_status, pro)) != hipSuccess) return e;
     if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[0], s);
     switch (p.sub_words) {
         case kSubWordsSmall:
@@ -1136,7 +1182,7 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
 
 hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
-                                 const std::function<void()>& follow_up, DecodeReport* report) {
+                                 const DecodeFollowUp& follow_up, DecodeReport* report) {
     switch (p.sub_words) {
         case kSubWordsSmall:
             return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.repair(follow_up, report);

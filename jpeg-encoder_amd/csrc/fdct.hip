@@ -305,7 +305,13 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
                                                                     const uint32_t* __restrict__ records, int width,
                                                                     int height, int blocks_w, uint32_t n_mcu,
                                                                     size_t image_bytes, QuantTables q,
-                                                                    uint8_t* __restrict__ rgb, ComponentMode mode) {
+                                                                    uint8_t* __restrict__ rgb, ComponentMode mode,
+                                                                    DecodeReportRelay relay) {
+    // the decoder's outcome, known since the kernels before this one ended, goes to the host on the side
+    if (relay.report != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        relay.report->unsettled = *relay.unsettled;
+        relay.report->status = *relay.status;
+    }
     // coefficients as rotated 16-byte chunks (as in the forward kernel); after the row step the
     // first half is reused for the samples, [channel][mcu][64] u8
     __shared__ __align__(16) uint8_t lds_coef[kFdctThreads * 128];
@@ -546,17 +552,18 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
 }
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
-                         const QuantTables& q, uint8_t* d_rgb, const uint32_t* d_records, ComponentMode mode) {
+                         const QuantTables& q, uint8_t* d_rgb, const uint32_t* d_records, ComponentMode mode,
+                         const DecodeReportRelay& relay) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
     if (d_records != nullptr)
         idct_dequant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu,
-                                                                image_bytes, q, d_rgb, mode);
+                                                                image_bytes, q, d_rgb, mode, relay);
     else
         idct_dequant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_coefs, nullptr, width, height, bw, n_mcu,
-                                                                 image_bytes, q, d_rgb, mode);
+                                                                 image_bytes, q, d_rgb, mode, relay);
 }
 
 void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc) {

@@ -47,16 +47,24 @@ struct DecodeTables {
 
 // The same four tables for the parallel decoder, whose inner loop wants everything about a symbol in
 // one word so that it needs no branches:
-//   byte 0  bits the symbol takes from the stream: code length + amplitude bits (1 when no code matches)
-//   byte 1  coefficient positions skipped before the value: the run of an AC symbol, 0 for DC symbols,
-//           kStepRunEob for the end-of-block symbol (far more than a block has)
-//   byte 2  code length
+//   byte 0  bits the entry takes from the stream: code length + amplitude bits (1 when no code matches),
+//           plus the length of the end-of-block code for a combined entry (below)
+//   byte 1  bits 0-6: coefficient positions skipped before the value: the run of an AC symbol, 0 for DC
+//           symbols and for the end-of-block symbol;  bit 7 (kStepEndsBlock): the block ends with this entry
+//   byte 2  bits 0-4: code length;  bits 5-7: 0, or for a combined entry the length of the end-of-block code
 //   byte 3  bits 0-4: 32 - amplitude bits (the shift that brings the amplitude down from the top of a word);
 //           kStepHasAmp, kStepBad, kStepDcAdd flags
 // fast[] is indexed by the next kFastBits stream bits.  Where longer codes start with those bits the entry
 // has byte 0 = 0 and points to a sub-table of slow[] indexed by the stream bits that follow:
 //   byte 1  mask for those bits (sub-table size - 1),  bytes 2-3  byte offset of the sub-table in the table
-constexpr uint32_t kStepRunEob = 127;
+// Combined entries: sparse blocks are a DC symbol, a few AC symbols and the end-of-block code, so most look-ups
+// of a smooth picture would be end-of-block codes.  Where a symbol with its amplitude bits AND the
+// end-of-block code of the same table class behind it fit into the kFastBits index bits, the entry stands for
+// both: a DC symbol (also one without amplitude bits) or an AC symbol with amplitude, then the end of the
+// block.  If such an AC symbol fills position 63 the block is complete without an end-of-block code (the bits
+// that look like one belong to the next block): the walker then gives the code's bits back (kStepEobLen).
+constexpr uint32_t kStepEndsBlock = 0x80u << 8;
+constexpr uint32_t kStepEobLenShift = 21;    // bits 21-23
 constexpr uint32_t kStepHasAmp = 1u << 29;   // amplitude bits follow the code
 constexpr uint32_t kStepBad = 1u << 30;      // no code word, or a symbol the format does not allow
 constexpr uint32_t kStepDcAdd = 1u << 31;    // DC symbol with amplitude bits (the sign bit: one compare)
@@ -66,7 +74,8 @@ struct StepTableT {
     uint32_t fast[1 << kFastBitsT];
     uint32_t slow[kSlowEntriesT];
 };
-using StepTableDc = StepTableT<9, 128>;    // DC codes are at most 11 bits long
+// Both tables take the same number of index bits, so the walker's shift is a constant.
+using StepTableDc = StepTableT<11, 4>;     // DC codes are at most 11 bits long: no sub-tables
 using StepTableAc = StepTableT<11, 256>;   // the Annex K AC codes beyond 11 bits fit eight 32-entry sub-tables
 struct StepClass {
     StepTableDc dc;
@@ -215,11 +224,38 @@ struct DecodeScratch {
                                    // write pass, [3] after follow_up
 };
 
+// Small jobs the decoder's first kernel does on the side (both optional).  A launch at the head of the chain
+// costs more than its run time, because there the GPU waits for the host.
+constexpr uint32_t kSeedWords = 48;
+struct DecodePrologue {
+    // The scan ranges as kernel arguments instead of a copy (which on a stream costs the latency of the copy
+    // engine): 3 * n_images <= kSeedWords words -- offsets | sizes | unstuffed bases -- that the kernel uses and
+    // leaves at d_offsets, where d_sizes = d_offsets + n and sc.ubase = d_offsets + 2 n must point.  0: the
+    // arrays are in device memory already.
+    const uint64_t* h_words = nullptr;
+    uint32_t n_words = 0;
+    // The header_bytes bytes in front of every scan, copied to headers_out back to back ([n][header_bytes];
+    // may be pinned host memory: the kernel then delivers the headers itself).  null: none.
+    uint8_t* headers_out = nullptr;
+    uint32_t header_bytes = 0;
+};
+
 // What the decoder tells the host, in host memory that the GPU can write (hipHostMalloc).
 struct DecodeReport {
     uint32_t unsettled;   // the last of the standard synchronisation rounds still changed something
     int32_t status;       // *d_status after the write pass
 };
+// What has to be copied into the report once the write pass has run.  The decoder hands this to the follow-up
+// work: a kernel launched behind the write pass can do the copy on the side (one thread, two words), which
+// saves the launch of a kernel that does nothing else.
+struct DecodeReportRelay {
+    const uint32_t* unsettled = nullptr;
+    const int32_t* status = nullptr;
+    DecodeReport* report = nullptr;   // null: nothing to relay
+};
+// Work that consumes the coefficients, enqueued behind the write pass.  Returns true when one of its kernels
+// relays the report (see launch_idct_dequant); otherwise the decoder launches a small kernel for that.
+using DecodeFollowUp = std::function<bool(const DecodeReportRelay&)>;
 
 // Enqueues the whole decode -- unstuffing, three synchronisation rounds, scan and write pass -- then
 // `follow_up` (work that consumes the coefficients; may be empty), then a copy of the outcome to
@@ -230,30 +266,19 @@ struct DecodeReport {
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
-                                 const std::function<void()>& follow_up, DecodeReport* report);
+                                 const DecodeFollowUp& follow_up, DecodeReport* report,
+                                 const DecodePrologue& prologue);
 
 // The decoder's first step on its own: the unstuffed copy of every stream (sc.ustream at sc.ubase[i]) and the
 // number of dropped bytes per stream (sc.img_drops).  Needs sc.chunk_drops, chunk_base, img_drops, ubase, ustream, changed.
 hipError_t launch_unstuff(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets, const uint64_t* d_sizes,
-                          const DecodePlan& plan, const DecodeScratch& sc, int32_t* d_status);
+                          const DecodePlan& plan, const DecodeScratch& sc, int32_t* d_status, const DecodePrologue& prologue);
 
 // For streams that the standard rounds did not settle: more rounds (waiting on the stream after each),
 // then the write pass, `follow_up` and the report again, and a final wait.
 hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
-                                 const std::function<void()>& follow_up, DecodeReport* report);
-
-// A few 64-bit words from the host to device memory as kernel arguments: a launch instead of a copy, which
-// on a stream costs the latency of the copy engine (count <= kSeedWords).
-constexpr uint32_t kSeedWords = 48;
-void launch_seed_words(hipStream_t s, uint64_t* d_dst, const uint64_t* h_words, uint32_t count);
-
-// Copies the header_bytes bytes in front of each scan (d_scan_offsets[i] is the scan's offset in
-// d_data) to d_out back to back, so that the host can validate all headers in one go.  d_out may be
-// pinned host memory: the kernel then delivers the headers itself, and no copy sits in the stream
-// between the decoder's kernels.
-void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
-                           uint32_t header_bytes, uint8_t* d_out);
+                                 const DecodeFollowUp& follow_up, DecodeReport* report);
 
 // d_records null: d_coefs is [image][mcu][channel][64].  Else the decoder's own layout: one 32-bit record
 // per block-channel, [image][mcu*3 + channel] = DC value (low 16 bits) | chunk mask << 16, and the chunk
@@ -263,7 +288,7 @@ void launch_gather_headers(hipStream_t s, const uint8_t* d_data, const uint64_t*
 // one 4-byte store for the decoder instead of a chunk and a mask byte.
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
                          const QuantTables& q, uint8_t* d_rgb, const uint32_t* d_records = nullptr,
-                         ComponentMode mode = ComponentMode{});
+                         ComponentMode mode = ComponentMode{}, const DecodeReportRelay& relay = DecodeReportRelay{});
 
 // Per-block (component granularity) launchers, blocks.hip.
 void launch_dct_forward_blocks(hipStream_t s, const uint8_t* d_in, size_t n, float* d_out);

@@ -30,5 +30,13 @@ for it in range(reps):
     dec = ctx.decode_batch(out, offs, sizes, w, h, lum, chrom)
 torch.cuda.synchronize(); t1 = time.perf_counter()
 print(f"{reps} calls back to back: {1e3*(t1-t0)/reps:.3f} ms per call  {reps*n*w*h/(t1-t0)/1e6:.0f} MPix/s")
+ctx.set_profiling(True)
+acc = None
+for it in range(20):
+    dec = ctx.decode_batch(out, offs, sizes, w, h, lum, chrom)
+    ph = ctx.last_phase_ms()
+    acc = ph if acc is None else [a + b for a, b in zip(acc, ph)]
+ctx.set_profiling(False)
+print("phases (us): unstuff %.1f  sync rounds %.1f  scan+write %.1f  inverse transform %.1f" % tuple(1e3 * a / 20 for a in acc[:4]))
 want = po.decode(out.cpu().numpy()[offs[0]:offs[0] + sizes[0]].tobytes(), w, h, q)
 print("matches oracle:", np.array_equal(dec.cpu().numpy().reshape(n, h, w, 3)[n - 1], want))
