@@ -346,12 +346,11 @@ __device__ __forceinline__ void load_tables(StepTables& t, const StepTables* __r
 
 constexpr uint32_t kClassBytes = sizeof(StepClass);    // luminance tables first, then chrominance
 constexpr uint32_t kAcBytes = sizeof(StepTableDc);     // DC table first, then AC
-static_assert(StepTableDc::kFastBits == StepTableAc::kFastBits, "one shift for both tables");
-constexpr uint32_t kStepShift = 32 - StepTableAc::kFastBits;
+constexpr uint32_t kDcShift = 32 - StepTableDc::kFastBits, kAcShift = 32 - StepTableAc::kFastBits;
 
-// `tab`: the table to use (in LDS), v: the next 32 stream bits.
-__device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v) {
-    uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> kStepShift) << 2));
+// `tab`: the table to use (in LDS), v: the next 32 stream bits, shift: 32 - the table's fast bits.
+__device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v, uint32_t shift) {
+    uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> shift) << 2));
     if ((e & 0xffu) == 0) e = *reinterpret_cast<const uint32_t*>(tab + (e >> 16) + (((v >> 16) & ((e >> 8) & 0xffu)) << 2));
     return e;
 }
@@ -390,11 +389,12 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
     const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
     uint32_t o0 = class_offset(lum_mask, c0), o1 = class_offset(lum_mask, c1), o2 = class_offset(lum_mask, c2);
     uint32_t k = z ? kAcBytes : 0u;     // DC table at the start of a block, AC table inside
+    uint32_t shift = z ? kAcShift : kDcShift;
     int nb = 0, a0 = 0, a1 = 0, a2 = 0;
     BitWindow<GroupWords<W>> win(gw, p);
     while (p < end) {
         const uint32_t v = win.peek(p);
-        const uint32_t e = step_lookup(tb + o0 + k, v);
+        const uint32_t e = step_lookup(tb + o0 + k, v, shift);
         p += e & 0xffu;
         // AC positions consumed including this entry, plus 128 when the entry ends the block
         const uint32_t processed = z + ((e >> 8) & 0xffu);
@@ -403,6 +403,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
         const bool done = processed >= 63u;                  // end of block, or the block is full
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
+        shift = done ? kDcShift : kAcShift;
         a0 += ((int32_t)e < 0) ? step_amplitude(v, e) : 0;   // kStepDcAdd
         nb += done ? 1 : 0;
         const uint32_t o = o0;
@@ -527,6 +528,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     int l1 = c1 == 0 ? wt.last0 : (c1 == 1 ? wt.last1 : wt.last2);
     int l2 = c2 == 0 ? wt.last0 : (c2 == 1 ? wt.last1 : wt.last2);
     uint32_t k = z ? kAcBytes : 0u;
+    uint32_t shift = z ? kAcShift : kDcShift;
     uint32_t block = wt.block;
     // Where chunk 0 of the current block and of the two after it go; rotated like the rest, so that no
     // block has to derive its place from its index.
@@ -558,7 +560,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
             bw.begin(d0, stride, record);
         }
         const uint32_t v = win.peek(p);
-        const uint32_t e = step_lookup(tb + o0 + k, v);
+        const uint32_t e = step_lookup(tb + o0 + k, v, shift);
         const bool is_dc = k == 0;
         p += e & 0xffu;
         // AC positions consumed including this entry, plus 128 when the entry ends the block (the end-of-block
@@ -571,6 +573,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
         const uint32_t position = processed & 0x7fu;
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
+        shift = done ? kDcShift : kAcShift;
         if (owning) {
             const int amp = (e & kStepHasAmp) ? step_amplitude(v, e) : 0;
             trouble |= processed | (e & kStepBad);
@@ -604,7 +607,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     wt.final_bit = final_bit;
 }
 
-constexpr uint32_t kMaxLocalIterations = 12;   // repair steps per launch; what is left is flagged pending
+constexpr uint32_t kMaxLocalIterations = 16;   // repair steps per launch; what is left is flagged pending
 
 template <uint32_t W>
 __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __restrict__ ustream,

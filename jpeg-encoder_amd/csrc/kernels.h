@@ -74,8 +74,9 @@ struct StepTableT {
     uint32_t fast[1 << kFastBitsT];
     uint32_t slow[kSlowEntriesT];
 };
-// Both tables take the same number of index bits, so the walker's shift is a constant.
-using StepTableDc = StepTableT<11, 4>;     // DC codes are at most 11 bits long: no sub-tables
+// Table sizes are LDS: with 23 KB of tables three workgroups of the write pass fit a compute unit, with 34 KB
+// (eleven index bits for the DC tables too) only two, and a 4K picture of noise decoded in 0.78 instead of 0.70 ms.
+using StepTableDc = StepTableT<9, 128>;    // DC codes are at most 11 bits long
 using StepTableAc = StepTableT<11, 256>;   // the Annex K AC codes beyond 11 bits fit eight 32-entry sub-tables
 struct StepClass {
     StepTableDc dc;

@@ -9,7 +9,17 @@ import pyoracle as po
 import torch
 
 w, h, q, mode, n = (int(a) for a in sys.argv[1:6])
+if os.environ.get("JEA_LIB"):   # a build made by tools/build_variant.sh
+    jea.binding.LIB_PATH = os.path.join(ROOT, "jpeg-encoder_amd", os.environ["JEA_LIB"])
 ctx = jea.Context(0)
+if os.environ.get("JEA_LIB"):   # probe builds may decode nonsense on purpose: only their kernel times matter
+    _decode = ctx.decode_batch
+    def _tolerant(*a):
+        try:
+            return _decode(*a)
+        except jea.JeaError:
+            return None
+    ctx.decode_batch = _tolerant
 lum, chrom = jea.binding.quant_tables(q)
 if mode == 2:
     from bench import photo_like_image
@@ -39,4 +49,4 @@ for it in range(20):
 ctx.set_profiling(False)
 print("phases (us): unstuff %.1f  sync rounds %.1f  scan+write %.1f  inverse transform %.1f" % tuple(1e3 * a / 20 for a in acc[:4]))
 want = po.decode(out.cpu().numpy()[offs[0]:offs[0] + sizes[0]].tobytes(), w, h, q)
-print("matches oracle:", np.array_equal(dec.cpu().numpy().reshape(n, h, w, 3)[n - 1], want))
+print("matches oracle:", dec is not None and np.array_equal(dec.cpu().numpy().reshape(n, h, w, 3)[n - 1], want))
