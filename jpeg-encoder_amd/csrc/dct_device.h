@@ -158,7 +158,9 @@ __device__ __forceinline__ void colour_inverse(int Y, int Cb, int Cr, uint8_t& r
 // two f32 FMAs at magnitudes below 512 (roundings of at most 2^-16 each, constants 1.8 * 128 * 2^-24):
 // |q - true| < e = 5e-5 < d = 1e-4, and the test is fract(q) < 2e-4 as there.  Values still need the
 // clamp to [0, 255] (:49-51); they are integers, so the conversion to bytes is exact.
-__device__ __forceinline__ void colour_inverse_fast(float Y, float Cb, float Cr, float& r, float& g, float& b, bool& tie) {
+// This variant leaves the clamp to the caller: r, g, b are whole numbers between about -180 and 435.
+__device__ __forceinline__ void colour_inverse_fast_unclamped(float Y, float Cb, float Cr, float& r, float& g, float& b,
+                                                              bool& tie) {
     const float cb = Cb - 128.0f, cr = Cr - 128.0f;
     const float y = Y + (0.5f + 1e-4f);
     const float qr = __builtin_fmaf(1.402f, cr, y);
@@ -166,12 +168,20 @@ __device__ __forceinline__ void colour_inverse_fast(float Y, float Cb, float Cr,
     const float qg = __builtin_fmaf(-0.714136f, cr, __builtin_fmaf(-0.344136f, cb, y));
     const float fr = __builtin_amdgcn_fractf(qr), fb = __builtin_amdgcn_fractf(qb), fg = __builtin_amdgcn_fractf(qg);
     tie = min3(fr, fb, fg) < 2e-4f;
-    r = __builtin_amdgcn_fmed3f(qr - fr, 0.0f, 255.0f);
-    b = __builtin_amdgcn_fmed3f(qb - fb, 0.0f, 255.0f);
-    g = __builtin_amdgcn_fmed3f(qg - fg, 0.0f, 255.0f);
+    r = qr - fr;
+    b = qb - fb;
+    g = qg - fg;
+}
+__device__ __forceinline__ void colour_inverse_fast(float Y, float Cb, float Cr, float& r, float& g, float& b, bool& tie) {
+    colour_inverse_fast_unclamped(Y, Cb, Cr, r, g, b, tie);
+    r = __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
+    b = __builtin_amdgcn_fmed3f(b, 0.0f, 255.0f);
+    g = __builtin_amdgcn_fmed3f(g, 0.0f, 255.0f);
 }
 
-// byte `index` (0..3) of `word` replaced by the value, an integer in [0, 255] held as a float
+// Byte `index` (0..3) of `word` replaced by the value, a whole number held as a float.  v_cvt_pk_u8_f32
+// saturates: whole numbers below 0 give 0 and above 255 give 255 (checked for -2^20..2^20 on the GPU,
+// tools/probe_insts.hip), so a clamp in front of it is redundant.
 __device__ __forceinline__ uint32_t insert_byte(float value, uint32_t index, uint32_t word) {
     return __builtin_amdgcn_cvt_pk_u8_f32(value, index, word);
 }

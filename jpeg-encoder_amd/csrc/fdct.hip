@@ -285,10 +285,10 @@ __device__ __forceinline__ void idct_cols(const float (&tmp)[8][8], uint8_t* __r
             float acc = inv_c(0, y) * tmp[x][0];
 #pragma unroll
             for (int v = 1; v < kRows; ++v) acc += inv_c(v, y) * tmp[x][v];
-            // :144-154: below -128 -> -128, above 127 -> 127, else truncation toward zero; clamping first
-            // gives the same integer without branches
-            const int o = (int)__builtin_amdgcn_fmed3f(acc, -128.0f, 127.0f);
-            packed[x >> 2] |= (uint32_t)(o + 128) << (8 * (x & 3));
+            // :144-154: below -128 -> -128, above 127 -> 127, else truncation toward zero; then + 128 (:21-27).
+            // Truncating first and letting the byte conversion saturate gives the same byte: a sum below
+            // -128 truncates to at most -128, i.e. at most 0 after the shift, one above 127 to at least 255
+            packed[x >> 2] = insert_byte(__builtin_truncf(acc) + 128.0f, x & 3, packed[x >> 2]);
         }
         *reinterpret_cast<uint2*>(px + y * 8) = make_uint2(packed[0], packed[1]);
     }
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
                     px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
                 } else {
                     bool tie;
-                    colour_inverse_fast((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);
+                    colour_inverse_fast_unclamped((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);   // insert_byte clamps
                     if (__builtin_expect(__any(tie), 0)) {   // the literal formula
                         uint8_t rr, gg, bb;
                         colour_inverse(c0, c1, c2, rr, gg, bb);
