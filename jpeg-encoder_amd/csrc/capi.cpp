@@ -83,7 +83,7 @@ struct jea_ctx {
     DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
     // parallel decode
     DeviceBuffer ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
-        round_flags, grp_pending, sub_guess, first_bad, ctx_keys, ctx_vals;
+        round_flags, grp_pending, grp_end, sub_guess, first_bad, ctx_keys, ctx_vals;
     DeviceBuffer tile_ff8;
     void* pin_io = nullptr;   // pinned staging for the host-buffer entry points
     size_t pin_io_bytes = 0;
@@ -524,7 +524,7 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->seg_offsets, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small,
                             &ctx->ustream, &ctx->chunk_drops, &ctx->chunk_base, &ctx->img_drops,
                             &ctx->sub_end, &ctx->sub_used, &ctx->sub_info, &ctx->grp_sum, &ctx->grp_base,
-                            &ctx->round_flags, &ctx->grp_pending, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
+                            &ctx->round_flags, &ctx->grp_pending, &ctx->grp_end, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
                             &ctx->ctx_vals, &ctx->tile_ff8})
         free_buffer(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1187,6 +1187,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     if ((rc = ensure(ctx, ctx->round_flags, 4 * sizeof(uint32_t)))) return rc;
     constexpr uint32_t kContextSlots = 1u << 18;
     if ((rc = ensure(ctx, ctx->grp_pending, n_images * plan.n_groups * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->grp_end, n_images * plan.n_groups * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->sub_guess, n_images * subs * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->first_bad, n_images * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ctx_keys, kContextSlots * sizeof(unsigned long long)))) return rc;
@@ -1240,6 +1241,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.out_records = d_block_records;
     sc.mode = ctx->mode;
     sc.grp_pending = (uint32_t*)ctx->grp_pending.ptr;
+    sc.grp_end = (uint32_t*)ctx->grp_end.ptr;
     sc.sub_guess = (uint32_t*)ctx->sub_guess.ptr;
     sc.first_bad = (uint32_t*)ctx->first_bad.ptr;
     sc.ctx_keys = (unsigned long long*)ctx->ctx_keys.ptr;
@@ -1250,14 +1252,23 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
         JEA_HIP(ctx, hipEventRecord(ctx->marks[0], ctx->stream));
         sc.marks = ctx->marks + 1;
     }
+    // First without an unstuffed copy (the kernels read the raw scans).  A stream that two synchronisation rounds
+    // do not settle -- exactly periodic ones, mostly -- goes through the variant with an unstuffing pass, which
+    // has the repair rounds.
     JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
-                                       ctx->d_status, follow_up, report, prologue));
+                                       ctx->d_status, follow_up, report, prologue, true));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->profiling) ctx->n_marks = 5;   // unstuffing | synchronisation rounds | scan and write pass | follow-up
     if (with_headers && (rc = headers_ok())) return rc;
-    if (report->unsettled != 0)
-        JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs, ctx->d_status,
-                                           follow_up, report));
+    if (report->unsettled != 0) {
+        sc.marks = nullptr;
+        JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
+                                           ctx->d_status, follow_up, report, prologue, false));
+        JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (report->unsettled != 0)
+            JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs, ctx->d_status,
+                                               follow_up, report));
+    }
     return report_status(ctx, report->status, what);
 }
 

@@ -107,14 +107,36 @@ __device__ __forceinline__ Sums block_exclusive_scan(Sums v, Sums* lds4, Sums& t
 // by its 0x00); the rule matters for damaged streams, which must decode, or fail, as the reference's would.
 // The run that ends just before this piece is counted backwards, 4096 bytes at most: an unstuffed stream
 // with that many one-bits in a row holds no valid code word, so such a stream fails either way.
-__device__ __forceinline__ uint32_t drop_mask16(const uint8_t* __restrict__ file, uint64_t len, uint64_t scan_end,
-                                                uint64_t j0, uint8_t* bytes) {
-    uint32_t odd = 0;   // length of the run of 0xFF bytes that ends at the previous byte, modulo 2
+// Length, modulo 2, of the run of 0xFF bytes that ends at byte j0 - 1.
+__device__ __forceinline__ uint32_t ff_run_parity_before(const uint8_t* __restrict__ file, uint64_t len, uint64_t j0) {
+    uint32_t odd = 0;
     if (j0 >= 1 && j0 - 1 < len && file[j0 - 1] == 0xFFu) {
         uint32_t run = 1;
         while (run < 4096u && run < j0 && file[j0 - 1 - run] == 0xFFu) ++run;
         odd = run & 1u;
     }
+    return odd;
+}
+
+// drop_mask16 for a piece that lies inside the file and is already in registers (byte k of the piece is byte
+// k & 3 of word k >> 2, as loaded); `odd` = ff_run_parity_before(j0).
+__device__ __forceinline__ uint32_t drop_mask16_loaded(uint4 piece, uint32_t odd, uint64_t j0, uint64_t scan_end,
+                                                       uint8_t* bytes) {
+    const uint32_t w[4] = {piece.x, piece.y, piece.z, piece.w};
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        bytes[k] = (uint8_t)b;
+        if (b == 0u && odd && j0 + k - 1 < scan_end) mask |= 1u << k;
+        odd = (b == 0xFFu) ? (odd ^ 1u) : 0u;
+    }
+    return mask;
+}
+
+__device__ __forceinline__ uint32_t drop_mask16(const uint8_t* __restrict__ file, uint64_t len, uint64_t scan_end,
+                                                uint64_t j0, uint8_t* bytes) {
+    uint32_t odd = ff_run_parity_before(file, len, j0);   // of the run of 0xFF bytes that ends at the previous byte
     uint32_t mask = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -299,6 +321,113 @@ __device__ __forceinline__ void stage_group(GroupWords<W, kTail>& gw, const uint
     }
 }
 
+// The same staging straight from the raw scan, for the decoder that works without an unstuffed copy in
+// memory.  There a workgroup owns a fixed range of RAW bytes, [group_raw0, group_raw0 + kOwned * 4W); the
+// stuffed zeros in it are dropped on the way into LDS, so the group holds a varying number of stream bytes and
+// of sub-sequences (the last one may be short).  Bit 0 of the staged window is `warm_bytes` stream bytes before
+// the group's first one (warm-up sub-sequences of the first synchronisation round; 0 otherwise): twice as many
+// raw bytes are examined in front of the group, since at most every second raw byte is a stuffed zero.
+// Behind the group the window takes whatever 2 * 4 * kTail raw bytes yield, at least the kTail words a walk
+// may look at.
+struct RawGroup {
+    uint32_t group_bytes;    // stream bytes of the group's own raw range
+    uint32_t window_bytes;   // stream bytes from the group's first one to the end of what was examined
+    bool end_in_window;      // the scan ends inside the examined range: window_bytes then ends the stream
+};
+template <uint32_t W, uint32_t kTail>
+__device__ __forceinline__ RawGroup stage_group_raw(GroupWords<W, kTail>& gw, const uint8_t* __restrict__ scan, uint64_t len,
+                                                    uint64_t group_raw0, uint32_t warm_bytes, uint32_t* __restrict__ scratch) {
+    using G = GroupWords<W, kTail>;
+    constexpr uint32_t kGroupRaw = kOwned * 4 * W;
+    constexpr uint32_t kTotalWords = sizeof(gw.w) / 4;
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < kTotalWords; i += kThreads) gw.w[i] = 0;
+    const uint64_t raw0 = group_raw0 - 2 * (uint64_t)warm_bytes;            // callers give warm-up only where this is >= 0
+    const uint32_t warm_pieces = 2 * warm_bytes / 16, group_pieces = kGroupRaw / 16;
+    const uint32_t pieces = warm_pieces + group_pieces + (2 * 4 * kTail + 15) / 16;
+    const uint64_t scan_end = len >= 2 ? len - 2 : 0;
+    uint32_t carry = 0, kept_warm = 0, kept_to_group_end = 0;
+    int32_t shift = 0;   // stream-byte index in the examined range -> byte index in the window
+    __syncthreads();     // the zeros are in place
+    for (uint32_t p0 = 0; p0 < pieces; p0 += kThreads) {
+        const uint32_t piece = p0 + tid;
+        const uint64_t j0 = raw0 + 16ull * piece;
+        uint8_t bytes[16];
+        uint32_t mask = 0, valid = 0;
+        // Nearly every piece lies inside the scan and holds no 0xFF byte: nothing to drop, and its sixteen
+        // bytes go out as whole words.  (The test may take a piece without 0xFF for one with: that is only slower.)
+        uint4 raw16 = make_uint4(0, 0, 0, 0);
+        bool plain = false;
+        if (piece < pieces && j0 + 16 <= len) {
+            __builtin_memcpy(&raw16, scan + j0, 16);
+            const bool after_ff = j0 > 0 && scan[j0 - 1] == 0xFFu;
+            const uint32_t n0 = ~raw16.x, n1 = ~raw16.y, n2 = ~raw16.z, n3 = ~raw16.w;   // a zero byte here was 0xFF
+            const uint32_t any_ff = (((n0 - 0x01010101u) & raw16.x) | ((n1 - 0x01010101u) & raw16.y) |
+                                     ((n2 - 0x01010101u) & raw16.z) | ((n3 - 0x01010101u) & raw16.w)) & 0x80808080u;
+            plain = any_ff == 0 && !after_ff;
+            valid = 16;
+            if (!plain) mask = drop_mask16_loaded(raw16, after_ff ? ff_run_parity_before(scan, len, j0) : 0u, j0, scan_end, bytes);
+        } else if (piece < pieces && j0 < len) {
+            mask = drop_mask16(scan, len, scan_end, j0, bytes);
+            valid = (uint32_t)(len - j0);
+        }
+        const uint32_t kept = valid - __popc(mask);
+        uint32_t incl = kept;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) scratch[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry + incl - kept;
+        for (int w = 0; w < wave; ++w) before += scratch[w];
+        const uint32_t round_total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        // stream bytes before the group's first raw byte, and up to the end of its raw range: both boundaries
+        // fall between pieces, and the warm-up pieces all lie in the first round
+        if (piece == warm_pieces) scratch[4] = before;
+        if (piece == warm_pieces + group_pieces) scratch[5] = before;
+        __syncthreads();
+        if (p0 == 0) {
+            kept_warm = scratch[4];
+            shift = (int32_t)warm_bytes - (int32_t)kept_warm;
+        }
+        if (warm_pieces + group_pieces >= p0 && warm_pieces + group_pieces < p0 + kThreads) kept_to_group_end = scratch[5];
+        int32_t q = (int32_t)before + shift;
+        if (plain && q >= 0 && (uint32_t)q + 16u <= G::kWords * 4u) {
+            // words of the window are MSB first: the piece's bytes as four such words, shifted to where they start
+            const uint32_t d0 = __builtin_bswap32(raw16.x), d1 = __builtin_bswap32(raw16.y), d2 = __builtin_bswap32(raw16.z),
+                           d3 = __builtin_bswap32(raw16.w);
+            const uint32_t w0 = ((uint32_t)q >> 2) + 1, sh = 8u * ((uint32_t)q & 3u);
+            atomicOr(&gw.w[G::slot(w0)], __builtin_amdgcn_alignbit(0u, d0, sh));
+            atomicOr(&gw.w[G::slot(w0 + 1)], __builtin_amdgcn_alignbit(d0, d1, sh));
+            atomicOr(&gw.w[G::slot(w0 + 2)], __builtin_amdgcn_alignbit(d1, d2, sh));
+            atomicOr(&gw.w[G::slot(w0 + 3)], __builtin_amdgcn_alignbit(d2, d3, sh));
+            if (sh) atomicOr(&gw.w[G::slot(w0 + 4)], __builtin_amdgcn_alignbit(d3, 0u, sh));
+        } else {
+            if (plain) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) bytes[k] = (uint8_t)((k < 4 ? raw16.x : (k < 8 ? raw16.y : (k < 12 ? raw16.z : raw16.w))) >> (8 * (k & 3)));
+            }
+            for (uint32_t k = 0; k < valid; ++k) {
+                if ((mask >> k) & 1u) continue;
+                if (q >= 0 && (uint32_t)q < G::kWords * 4u)
+                    atomicOr(&gw.w[G::slot(((uint32_t)q >> 2) + 1)], (uint32_t)bytes[k] << (8u * (3u - ((uint32_t)q & 3u))));
+                ++q;
+            }
+        }
+        carry += round_total;
+        __syncthreads();
+    }
+    RawGroup rg;
+    const uint64_t examined_end = raw0 + 16ull * pieces;
+    rg.end_in_window = len <= examined_end;
+    rg.window_bytes = carry - kept_warm;
+    rg.group_bytes = kept_to_group_end - kept_warm;   // pieces past the end of the scan keep nothing, so this holds there too
+    return rg;
+}
+
 // The 64 stream bits around the read position, in registers, and the word after them on its way from
 // LDS: the next symbol's bits never wait for a load.  With j = ceil(p / 32), `a` and `b` are stream
 // words j-1 and j (word -1 being the dummy), which hold bits p .. p+31 for every p with that j.
@@ -377,14 +506,15 @@ __device__ __forceinline__ uint32_t next_channel(uint32_t c) { return c == 2u ? 
 //
 // The loop body has no branches.  What depends on the channel -- table class, DC sum -- is kept in
 // three registers each, rotated when a block ends, so that the current channel's is always the first.
+// `limit`: the sub-sequence ends there at the latest (the end of a group that holds a short last sub-sequence).
 template <uint32_t W>
 __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTables& t, uint32_t lum_mask,
-                                         uint32_t sub, uint32_t state, Sums& sums) {
+                                         uint32_t sub, uint32_t state, Sums& sums, uint32_t limit = 0xffffffffu) {
     constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
     const uint32_t c0 = (state >> 8) & 3u;
     uint32_t z = (state >> 16) & 63u;
-    const uint32_t end = (sub + 1) * kSubBits;
+    const uint32_t end = min((sub + 1) * kSubBits, limit);
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(&t);
     const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
     uint32_t o0 = class_offset(lum_mask, c0), o1 = class_offset(lum_mask, c1), o2 = class_offset(lum_mask, c2);
@@ -514,12 +644,13 @@ struct BlockWriter {
 // most 26 bits (a damaged one included) and the walk cannot leave the staged window.
 template <uint32_t W, bool kPlanar>
 __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw, const StepTables& t, uint32_t* acc,
-                                             uint32_t lum_mask, uint32_t sub, uint32_t state, WriteTarget& wt) {
+                                             uint32_t lum_mask, uint32_t sub, uint32_t state, WriteTarget& wt,
+                                             uint32_t limit = 0xffffffffu) {
     constexpr uint32_t kSubBits = 32 * W;
     uint32_t p = sub * kSubBits + (state & 0xffu);
     const uint32_t c0 = (state >> 8) & 3u;
     uint32_t z = (state >> 16) & 63u;
-    const uint32_t end = (sub + 1) * kSubBits;
+    const uint32_t end = min((sub + 1) * kSubBits, limit);
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(&t);
     const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
     // table class and running DC of the current channel and the two after it (see walk)
@@ -609,7 +740,27 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
 
 constexpr uint32_t kMaxLocalIterations = 16;   // repair steps per launch; what is left is flagged pending
 
-template <uint32_t W>
+// What the kernels of the decoder that reads the raw scan need instead of the unstuffed copy.
+struct RawSource {
+    const uint8_t* scan = nullptr;       // all files; image i's scan starts at offsets[i] and is sizes[i] raw bytes long
+    const uint64_t* offsets = nullptr;
+    uint32_t* grp_end = nullptr;         // [n][n_groups] end state of each group's last sub-sequence
+};
+// Jobs the first kernel of the chain does on the side (see unstuff_count_kernel, which does them when there is
+// an unstuffing pass): clearing *status and *check_flag, scan ranges from kernel arguments, header gather.
+struct RawPrologue {
+    SegmentWords words;
+    uint32_t n_words = 0;
+    uint64_t* d_words = nullptr;
+    uint8_t* headers_out = nullptr;
+    uint32_t header_bytes = 0;
+    int32_t* status = nullptr;
+    uint32_t* check_flag = nullptr;
+};
+
+// kRaw: the stream is read from the raw scan (stage_group_raw); a group is then a range of raw bytes, holds
+// n_active <= kOwned sub-sequences, and hands its end state to the next group through raw.grp_end.
+template <uint32_t W, bool kRaw>
 __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __restrict__ ustream,
                                                                const uint64_t* __restrict__ ubase,
                                                                const uint64_t* __restrict__ sizes,
@@ -624,31 +775,58 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                const uint32_t* __restrict__ sub_guess,
                                                                const uint32_t* __restrict__ first_bad,
                                                                uint32_t lum_mask,
-                                                               uint32_t* __restrict__ changed) {
+                                                               uint32_t* __restrict__ changed, RawSource raw,
+                                                               RawPrologue pro) {
     constexpr uint32_t kSubBits = 32 * W;
+    constexpr uint32_t kGroupRaw = kOwned * 4 * W;
     __shared__ GroupWords<W> gw;
     __shared__ StepTables t;
     __shared__ uint32_t ends[kThreads + 1];   // ends[i] = state at the start of the sub-sequence in slot i
     __shared__ Sums red[4];
+    __shared__ uint32_t scratch[8];
 
     const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
-    const uint64_t ulen = sizes[img] - img_drops[img];
-    const uint64_t total_bits = 8 * ulen;
     const size_t group_index = (size_t)img * n_groups + group;
-    if ((uint64_t)group * kOwned * kSubBits >= total_bits) {   // nothing of the stream in this group
+    uint64_t raw_len = 0, raw_offset = 0, ulen = 0, total_bits = 0;
+    bool empty;
+    if (kRaw) {
+        if (first_round) {
+            if (group == 0 && img == 0 && tid == 0) {
+                *pro.status = 0;
+                *pro.check_flag = 0;
+            }
+            if (group == 0 && img == 0 && tid < pro.n_words) pro.d_words[tid] = pro.words.v[tid];
+        }
+        raw_offset = (first_round && pro.n_words) ? pro.words.v[img] : raw.offsets[img];
+        raw_len = (first_round && pro.n_words) ? pro.words.v[gridDim.y + img] : sizes[img];
+        if (first_round && pro.headers_out != nullptr && group == 0) {
+            const uint8_t* src = raw.scan + raw_offset - pro.header_bytes;
+            for (uint32_t i = tid; i < pro.header_bytes; i += kThreads) pro.headers_out[(size_t)img * pro.header_bytes + i] = src[i];
+        }
+        empty = (uint64_t)group * kGroupRaw >= raw_len;
+    } else {
+        ulen = sizes[img] - img_drops[img];
+        total_bits = 8 * ulen;
+        empty = (uint64_t)group * kOwned * kSubBits >= total_bits;
+    }
+    if (empty) {   // nothing of the stream in this group
         if (first_round && tid == 0) {
             grp_sum[group_index] = make_int4(0, 0, 0, 0);
             grp_pending[group_index] = 0;
         }
         return;
     }
-    // slot tid holds sub-sequence first_sub + tid; slots below kWarm belong to the previous group
+    // Classic: slot tid holds sub-sequence first_sub + tid; slots below kWarm belong to the previous group.
+    // Raw: the same, except that the first group has no warm-up slots in front: its owned sub-sequences start at slot 0.
     const int64_t first_sub = (int64_t)group * kOwned - kWarm;
     const int64_t sub = first_sub + tid;
     const bool owned = tid >= kWarm;
     const size_t sub_index = group_index * kOwned + (tid - kWarm);   // owned slots only
-    const bool in_stream = sub >= 0 && (uint64_t)sub * kSubBits < total_bits;
-    const bool active = in_stream && (owned || (first_round && group > 0));
+    const uint32_t warm_slots = (!kRaw || group > 0) ? kWarm : 0u;
+    const uint32_t slot = tid - kWarm + warm_slots;                  // of an owned thread; warm-up threads: tid
+    bool active;
+    if (kRaw) active = false;   // known after staging (first round) or from the records (later rounds)
+    else active = sub >= 0 && (uint64_t)sub * kSubBits < total_bits && (owned || (first_round && group > 0));
 
     uint32_t used = kNoState, my_end = 0, guess = kNoState;
     Sums sums{0, 0, 0, 0};
@@ -658,7 +836,12 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         // group before.  Guesses from the stream context (see context_guess_kernel) are tried on top.
         uint32_t entry = 0;
         bool need = false;
-        if (owned && active) {
+        if (kRaw) {
+            if (owned) {
+                used = sub_used[sub_index];
+                active = used != kNoState;    // the first round marked the slots the group does not fill
+            }
+        } else if (owned && active) {
             used = sub_used[sub_index];
             if (sub_guess != nullptr && (uint64_t)sub >= first_bad[img]) {
                 guess = sub_guess[sub_index];
@@ -667,7 +850,8 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
             need = guess != kNoState;
         }
         if (tid == kWarm) {
-            if (group > 0) entry = __atomic_load_n(&sub_end[sub_index - 1], __ATOMIC_RELAXED);
+            if (group > 0)
+                entry = __atomic_load_n(kRaw ? &raw.grp_end[group_index - 1] : &sub_end[sub_index - 1], __ATOMIC_RELAXED);
             need = need || (active && entry != used) || grp_pending[group_index] != 0;
         }
         if (!__syncthreads_or(need ? 1 : 0)) return;
@@ -676,8 +860,13 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
             const int4 si = sub_info[sub_index];
             sums = Sums{si.x, si.y, si.z, si.w};
         }
-        if (tid == kWarm) ends[kWarm] = entry;
-        if (owned) ends[tid + 1] = my_end;
+        if (kRaw) {
+            if (tid == kWarm) ends[warm_slots] = entry;
+            if (owned) ends[slot + 1] = my_end;
+        } else {
+            if (tid == kWarm) ends[kWarm] = entry;
+            if (owned) ends[tid + 1] = my_end;
+        }
     } else {
         // Every slot starts from the guess "state 0 at its first bit"; for the first slot of the
         // image that is the true state.  The warm-up slots of the first group lie before the
@@ -687,36 +876,46 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
     }
 
     load_tables(t, tables);
-    stage_group(gw, ustream + ubase[img], ulen, first_sub);
+    uint32_t limit = 0xffffffffu, n_active = kOwned;
+    if (kRaw) {
+        const RawGroup rg = stage_group_raw(gw, raw.scan + raw_offset, raw_len, (uint64_t)group * kGroupRaw,
+                                            warm_slots * 4 * W, scratch);
+        n_active = (rg.group_bytes * 8 + kSubBits - 1) / kSubBits;
+        limit = warm_slots * kSubBits + rg.group_bytes * 8;
+        if (first_round) active = owned ? (tid - kWarm) < n_active : group > 0;
+    } else {
+        stage_group(gw, ustream + ubase[img], ulen, first_sub);
+    }
     __syncthreads();
+    const uint32_t my_slot = (kRaw && owned) ? slot : tid;
 
     bool dirty = false;
     if (__syncthreads_or(guess != kNoState ? 1 : 0)) {
         // offered start states first; the loop below keeps them only where they fit their predecessors
         if (guess != kNoState) {
-            my_end = walk<W>(gw, t, lum_mask, tid, guess, sums);
+            my_end = walk<W>(gw, t, lum_mask, my_slot, guess, sums, limit);
             used = guess;
             dirty = true;
         }
         __syncthreads();
-        if (guess != kNoState) ends[tid + 1] = my_end;
+        if (guess != kNoState) ends[my_slot + 1] = my_end;
         __syncthreads();
     }
     uint32_t pending = 0;
     for (uint32_t iteration = 0;; ++iteration) {
-        const uint32_t start = ends[tid];
+        const uint32_t start = ends[my_slot];
         const bool redo = active && start != used;
         if (iteration == kMaxLocalIterations) {   // the rest of the repair is left to the next launch
             pending = __syncthreads_or(redo ? 1 : 0) ? 1u : 0u;
             break;
         }
         if (redo) {
-            my_end = walk<W>(gw, t, lum_mask, tid, start, sums);
+            my_end = walk<W>(gw, t, lum_mask, my_slot, start, sums, limit);
             used = start;
             dirty = true;
         }
         __syncthreads();
-        if (redo) ends[tid + 1] = my_end;
+        if (redo) ends[my_slot + 1] = my_end;
         if (!__syncthreads_or(redo ? 1 : 0)) break;
     }
 
@@ -726,6 +925,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         __atomic_store_n(&sub_end[sub_index], my_end, __ATOMIC_RELAXED);
         sub_used[sub_index] = used;
         sub_info[sub_index] = make_int4(sums.nb, sums.dc0, sums.dc1, sums.dc2);
+        if (kRaw && (tid - kWarm) + 1 == n_active) __atomic_store_n(&raw.grp_end[group_index], my_end, __ATOMIC_RELAXED);
     } else if (first_round && owned) {   // sub-sequences past the end of the stream
         sub_end[sub_index] = 0;
         sub_used[sub_index] = kNoState;
@@ -844,13 +1044,17 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
                                                                uint32_t sub_bits, const uint32_t* __restrict__ sub_end,
                                                                const uint32_t* __restrict__ sub_used,
                                                                const uint32_t* __restrict__ grp_pending,
-                                                               uint32_t* __restrict__ unsettled) {
+                                                               uint32_t* __restrict__ unsettled,
+                                                               const uint32_t* __restrict__ raw_grp_end) {
     __shared__ Sums lds4[4];
     __shared__ Sums carry_s;
     const uint32_t img = blockIdx.x;
     if (threadIdx.x == 0) carry_s = Sums{0, 0, 0, 0};
     __syncthreads();
-    const uint64_t total_bits = unsettled != nullptr ? 8 * (sizes[img] - img_drops[img]) : 0;
+    // raw_grp_end given: the decoder that reads the raw scan -- a group is kOwned * sub_bits / 8 raw bytes, and the
+    // state it hands on is in raw_grp_end
+    const bool raw = raw_grp_end != nullptr;
+    const uint64_t total_bits = unsettled != nullptr ? 8 * (raw ? sizes[img] : sizes[img] - img_drops[img]) : 0;
     bool open_end = false;
     for (uint32_t g0 = 0; g0 < n_groups; g0 += kThreads) {
         const uint32_t g = g0 + threadIdx.x;
@@ -860,7 +1064,8 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
             v = Sums{s.x, s.y, s.z, s.w};
             if (unsettled != nullptr && (uint64_t)g * kOwned * sub_bits < total_bits) {
                 const size_t first = ((size_t)img * n_groups + g) * kOwned;
-                const uint32_t entry = g > 0 ? sub_end[first - 1] : 0u;   // the stream starts in state 0
+                uint32_t entry = 0;   // the stream starts in state 0
+                if (g > 0) entry = raw ? raw_grp_end[(size_t)img * n_groups + g - 1] : sub_end[first - 1];
                 open_end = open_end || entry != sub_used[first] || grp_pending[(size_t)img * n_groups + g] != 0;
             }
         }
@@ -883,7 +1088,7 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
 // stream held enough blocks.
 constexpr uint32_t kFoldGroups = 1024;
 
-template <uint32_t W, bool kPlanar, bool kFold>
+template <uint32_t W, bool kPlanar, bool kFold, bool kRaw>
 __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* __restrict__ ustream,
                                                                 const uint64_t* __restrict__ ubase,
                                                                 const uint64_t* __restrict__ sizes,
@@ -899,20 +1104,26 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const int4* __restrict__ grp_sum,
                                                                 const uint32_t* __restrict__ sub_end,
                                                                 const uint32_t* __restrict__ grp_pending,
-                                                                uint32_t* __restrict__ unsettled) {
+                                                                uint32_t* __restrict__ unsettled, RawSource raw) {
     constexpr uint32_t kSubBits = 32 * W;
+    constexpr uint32_t kGroupRaw = kOwned * 4 * W;
     __shared__ GroupWords<W, kWriteTail> gw;
     __shared__ StepTables t;
     __shared__ Sums lds4[4];
     __shared__ __align__(8) uint32_t acc[kThreads * kAccWords];
+    __shared__ uint32_t scratch[8];
 
     const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
-    const uint64_t ulen = sizes[img] - img_drops[img];
+    // classic: lengths of the unstuffed stream; raw: raw_len is the scan's length in the file
+    const uint64_t raw_len = sizes[img];
+    const uint64_t ulen = kRaw ? 0 : raw_len - img_drops[img];
     const uint64_t total_bits = 8 * ulen;
-    if ((uint64_t)group * kOwned * kSubBits >= total_bits) {
+    const bool empty = kRaw ? (uint64_t)group * kGroupRaw >= raw_len : (uint64_t)group * kOwned * kSubBits >= total_bits;
+    if (empty) {
         if (kFold && group == 0 && tid == 0 && total_blocks != 0) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);   // an empty stream
         return;
     }
+    const bool holds_end = kRaw ? (uint64_t)(group + 1) * kGroupRaw >= raw_len : (uint64_t)(group + 1) * kOwned * kSubBits >= total_bits;
     int4 gb;
     if (kFold) {
         Sums before{0, 0, 0, 0};
@@ -932,12 +1143,13 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
         if (tid == 0) {
             const size_t first = ((size_t)img * n_groups + group) * kOwned;
             if (unsettled != nullptr) {
-                const uint32_t entry = group > 0 ? sub_end[first - 1] : 0u;   // the stream starts in state 0
+                uint32_t entry = 0;   // the stream starts in state 0
+                if (group > 0) entry = kRaw ? raw.grp_end[(size_t)img * n_groups + group - 1] : sub_end[first - 1];
                 if (entry != sub_used[first] || grp_pending[(size_t)img * n_groups + group] != 0) atomicOr(unsettled, 1u);
             }
             // the workgroup that holds the end of the stream: fewer blocks than the picture needs is a stream
             // error (the serial decoder would run off the end of the file)
-            if ((uint64_t)(group + 1) * kOwned * kSubBits >= total_bits) {
+            if (holds_end) {
                 const int4 own = grp_sum[(size_t)img * n_groups + group];
                 if ((uint32_t)(before.nb + own.x) < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
             }
@@ -948,15 +1160,23 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     if ((uint32_t)gb.x >= total_blocks) return;   // the picture is complete before this group
     // slot tid holds the group's tid-th sub-sequence; the last kWarm threads have none
     const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + tid;
-    const uint64_t first_bit = ((uint64_t)group * kOwned + tid) * kSubBits;
-    const bool active = tid < kOwned && first_bit < total_bits;
 
     // asked for first, so that they are under way while tables and stream are staged
     const int4 si = tid < kOwned ? sub_info[sub_index] : make_int4(0, 0, 0, 0);
     const uint32_t start_state = tid < kOwned ? sub_used[sub_index] : 0u;
     load_tables(t, tables);
-    const uint8_t* stream = ustream + ubase[img];
-    stage_group(gw, stream, ulen, (int64_t)group * kOwned);
+    const uint8_t* stream = kRaw ? nullptr : ustream + ubase[img];
+    bool active;
+    uint32_t limit = 0xffffffffu;
+    RawGroup rg{0, 0, false};
+    if (kRaw) {
+        rg = stage_group_raw(gw, raw.scan + raw.offsets[img], raw_len, (uint64_t)group * kGroupRaw, 0u, scratch);
+        limit = rg.group_bytes * 8;
+        active = tid < kOwned && (uint64_t)tid * kSubBits < limit;
+    } else {
+        stage_group(gw, stream, ulen, (int64_t)group * kOwned);
+        active = tid < kOwned && ((uint64_t)group * kOwned + tid) * kSubBits < total_bits;
+    }
     for (uint32_t i = 0; i < kAccWords; ++i) acc[tid * kAccWords + i] = 0;
 
     Sums total;
@@ -975,21 +1195,34 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     wt.final_bit = 0;
     if (!active || wt.block >= total_blocks) return;
 
-    write_blocks<W, kPlanar>(gw, t, acc + tid * kAccWords, lum_mask, tid, start_state, wt);
+    write_blocks<W, kPlanar>(gw, t, acc + tid * kAccWords, lum_mask, tid, start_state, wt, limit);
     if (wt.error) {
         // a malformed symbol outranks a missing end marker, as in the serial order of checks
         const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
         if (old == JEA_ERR_NO_EOI) atomicCAS(status, JEA_ERR_NO_EOI, JEA_ERR_BAD_STREAM);
     }
     if (wt.finished) {
-        const uint64_t end_bit = (uint64_t)group * kOwned * kSubBits + wt.final_bit;
-        if (end_bit > total_bits) {   // bits past the end of the file were consumed
+        // positions from here on are relative to the group's first stream bit
+        bool overrun, marker;
+        const uint32_t q = (wt.final_bit + 7) >> 3;   // encoder.cpp:62-65: skip to the byte boundary, the next two bytes must be the EOI marker
+        if (kRaw) {
+            overrun = rg.end_in_window && wt.final_bit > 8 * rg.window_bytes;
+            const uint8_t* wb = reinterpret_cast<const uint8_t*>(gw.w);
+            using G = GroupWords<W, kWriteTail>;
+            const uint32_t b0 = wb[G::slot((q >> 2) + 1) * 4u + (3u - (q & 3u))];
+            const uint32_t b1 = wb[G::slot(((q + 1) >> 2) + 1) * 4u + (3u - ((q + 1) & 3u))];
+            marker = !(rg.end_in_window && q + 2 > rg.window_bytes) && b0 == 0xFFu && b1 == 0xD9u;
+        } else {
+            const uint64_t end_bit = (uint64_t)group * kOwned * kSubBits + wt.final_bit;
+            const uint64_t qq = (end_bit + 7) >> 3;
+            overrun = end_bit > total_bits;
+            marker = !overrun && qq + 2 <= ulen && stream[qq] == 0xFFu && stream[qq + 1] == 0xD9u;
+        }
+        if (overrun) {   // bits past the end of the file were consumed
             const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
             if (old == JEA_ERR_NO_EOI) atomicCAS(status, JEA_ERR_NO_EOI, JEA_ERR_BAD_STREAM);
-        } else {
-            // encoder.cpp:62-65: skip to the byte boundary, the next two bytes must be the EOI marker
-            const uint64_t q = (end_bit + 7) >> 3;
-            if (q + 2 > ulen || stream[q] != 0xFFu || stream[q + 1] != 0xD9u) atomicCAS(status, 0, JEA_ERR_NO_EOI);
+        } else if (!marker) {
+            atomicCAS(status, 0, JEA_ERR_NO_EOI);
         }
     }
 }
@@ -1062,32 +1295,64 @@ struct DecodeRun {
     const StepTables* d_tables;
     int16_t* d_coefs;
     int32_t* d_status;
+    // reading the raw scan (no unstuffed copy): the files, the scans' offsets in them, and the first kernel's side jobs
+    bool raw = false;
+    const uint8_t* d_scan = nullptr;
+    const uint64_t* d_offsets = nullptr;
+    const DecodePrologue* prologue = nullptr;
 
     dim3 grid() const { return dim3(p.n_groups, p.n_images); }
+    RawSource source() const { return raw ? RawSource{d_scan, d_offsets, sc.grp_end} : RawSource{}; }
     void sync_round(int first, uint32_t* flag, bool with_guesses) const {
-        decode_sync_kernel<W><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
-                                                         d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
-                                                         sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
-                                                         sc.first_bad, sc.mode.lum_mask, flag);
+        if (raw) {
+            RawPrologue rp{};
+            if (first) {
+                rp.status = d_status;
+                rp.check_flag = sc.changed + 2;
+                if (prologue != nullptr) {
+                    for (uint32_t i = 0; i < prologue->n_words; ++i) rp.words.v[i] = prologue->h_words[i];
+                    rp.n_words = prologue->n_words;
+                    rp.d_words = const_cast<uint64_t*>(d_offsets);
+                    rp.headers_out = prologue->headers_out;
+                    rp.header_bytes = prologue->header_bytes;
+                }
+            }
+            decode_sync_kernel<W, true><<<grid(), kThreads, 0, s>>>(nullptr, nullptr, d_sizes, nullptr, p.n_groups, first, d_tables,
+                                                                   sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
+                                                                   sc.grp_pending, nullptr, nullptr, sc.mode.lum_mask, flag,
+                                                                   source(), rp);
+        } else {
+            decode_sync_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
+                                                                    d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
+                                                                    sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
+                                                                    sc.first_bad, sc.mode.lum_mask, flag, RawSource{}, RawPrologue{});
+        }
     }
-    template <bool kPlanar, bool kFold>
+    template <bool kPlanar, bool kFold, bool kRaw>
     void write(uint32_t* check) const {
-        decode_write_kernel<W, kPlanar, kFold><<<grid(), kThreads, 0, s>>>(
+        decode_write_kernel<W, kPlanar, kFold, kRaw><<<grid(), kThreads, 0, s>>>(
             sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, p.total_blocks, d_tables, sc.sub_used, sc.sub_info,
             sc.grp_base, d_coefs, kPlanar ? sc.out_records : nullptr, sc.mode.lum_mask, d_status, sc.grp_sum, sc.sub_end,
-            sc.grp_pending, check);
+            sc.grp_pending, check, source());
     }
+    // The unstuffed-copy decoder is the fall-back for streams that need repair rounds: it always scans in a launch
+    // of its own.
     void scan_and_write(uint32_t* check = nullptr) const {
-        const bool fold = p.n_groups <= kFoldGroups;
+        const bool fold = raw && p.n_groups <= kFoldGroups;
         if (!fold)
             scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
                                                                d_status, d_sizes, sc.img_drops, 32 * W, sc.sub_end,
-                                                               sc.sub_used, sc.grp_pending, check);
+                                                               sc.sub_used, sc.grp_pending, check, raw ? sc.grp_end : nullptr);
         const bool planar = sc.out_records != nullptr;
-        if (planar && fold) write<true, true>(check);
-        else if (planar) write<true, false>(check);
-        else if (fold) write<false, true>(check);
-        else write<false, false>(check);
+        if (raw) {
+            if (planar && fold) write<true, true, true>(check);
+            else if (planar) write<true, false, true>(check);
+            else if (fold) write<false, true, true>(check);
+            else write<false, false, true>(check);
+        } else {
+            if (planar) write<true, false, false>(check);
+            else write<false, false, false>(check);
+        }
     }
 
     // Two rounds up front: the first decodes everything, the second repairs the starts of the
@@ -1169,17 +1434,18 @@ hipError_t launch_unstuff(hipStream_t s, const uint8_t* d_scan, const uint64_t* 
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& p, const DecodeScratch& sc,
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
-                                 const DecodeFollowUp& follow_up, DecodeReport* report, const DecodePrologue& pro) {
+                                 const DecodeFollowUp& follow_up, DecodeReport* report, const DecodePrologue& pro, bool raw) {
     hipError_t e;
-    if ((e = launch_unstuff(s, d_scan, d_offsets, d_sizes, p, sc, d_status, pro)) != hipSuccess) return e;
+    if (pro.n_words > kSeedWords || (pro.n_words != 0 && pro.n_words != 3 * p.n_images)) return hipErrorInvalidValue;
+    if (!raw && (e = launch_unstuff(s, d_scan, d_offsets, d_sizes, p, sc, d_status, pro)) != hipSuccess) return e;
     if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[0], s);
     switch (p.sub_words) {
         case kSubWordsSmall:
-            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);
+            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro}.first_pass(follow_up, report);
         case kSubWordsMedium:
-            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);
+            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro}.first_pass(follow_up, report);
         default:
-            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.first_pass(follow_up, report);
+            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro}.first_pass(follow_up, report);
     }
 }
 

@@ -212,6 +212,7 @@ struct DecodeScratch {
     int4* grp_base;          // [n][n_groups] exclusive scan
     uint32_t* changed;       // [4] round flags
     uint32_t* grp_pending;   // [n][n_groups] workgroup ran out of repair steps in the last round
+    uint32_t* grp_end;       // [n][n_groups] raw decoder: end state of the group's last sub-sequence
     uint32_t* sub_guess;     // [n][subs] start states offered from the stream context
     uint32_t* first_bad;     // [n] first sub-sequence that is not proven yet
     unsigned long long* ctx_keys;   // [ctx_slots] context hash table (power-of-two size): keys ...
@@ -258,17 +259,21 @@ struct DecodeReportRelay {
 // relays the report (see launch_idct_dequant); otherwise the decoder launches a small kernel for that.
 using DecodeFollowUp = std::function<bool(const DecodeReportRelay&)>;
 
-// Enqueues the whole decode -- unstuffing, three synchronisation rounds, scan and write pass -- then
-// `follow_up` (work that consumes the coefficients; may be empty), then a copy of the outcome to
-// *report, and returns without waiting.  Every block of d_coefs is written (chunk-planar: chunk 0 and
-// the non-zero chunks); *d_status is cleared first and receives the errors.  After the stream has been waited on:
-// report->unsettled == 0 is the usual case and the coefficients are final; otherwise
-// repair_entropy_decode has to run.
+// Enqueues the whole decode -- two synchronisation rounds, (scan and) write pass -- then `follow_up` (work that
+// consumes the coefficients; may be empty), then a copy of the outcome to *report, and returns without
+// waiting.  Every block of d_coefs is written (chunk-planar: chunk 0 and the non-zero chunks); *d_status is
+// cleared first and receives the errors.
+//   raw = true   the kernels read the raw scans and drop the stuffed bytes on their way into LDS: no unstuffing
+//                pass, no unstuffed copy in memory.  After the stream has been waited on, report->unsettled == 0
+//                is the usual case and the coefficients are final; otherwise the stream needs repair rounds,
+//                which only the other variant has: call again with raw = false.
+//   raw = false  an unstuffing pass first (launch_unstuff), then the same on the unstuffed copy.  If
+//                report->unsettled != 0 afterwards, repair_entropy_decode has to run.
 hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uint64_t* d_offsets,
                                  const uint64_t* d_sizes, const DecodePlan& plan, const DecodeScratch& sc,
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const DecodeFollowUp& follow_up, DecodeReport* report,
-                                 const DecodePrologue& prologue);
+                                 const DecodePrologue& prologue, bool raw);
 
 // The decoder's first step on its own: the unstuffed copy of every stream (sc.ustream at sc.ubase[i]) and the
 // number of dropped bytes per stream (sc.img_drops).  Needs sc.chunk_drops, chunk_base, img_drops, ubase, ustream, changed.

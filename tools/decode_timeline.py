@@ -8,16 +8,16 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = n.replace("(anonymous namespace)::", "").split("(")[0]
     return n.split("::")[-1].split("<")[0]
-# a decode call starts with the kernel that appears first in the trace among the library's decode kernels
-FIRST = next(short(r["Kernel_Name"]) for r in rows if "seed_words" in r["Kernel_Name"] or "unstuff_count" in r["Kernel_Name"] or "gather_headers" in r["Kernel_Name"])
-calls, cur = [], None
+# a decode call ends with the inverse transform; kernels of the encode that made the file come before the first call
+calls, cur = [], []
 for r in rows:
     k = short(r["Kernel_Name"])
-    if k == FIRST:
-        cur = []
+    if k.startswith("__amd") and not cur:
+        continue
+    cur.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    if k == "idct_dequant_kernel":
         calls.append(cur)
-    if cur is not None:
-        cur.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        cur = []
 calls = [c for c in calls if len(c) == len(calls[len(calls) // 2])][5:-5]
 n = len(calls[0])
 print("%d calls of %d kernels" % (len(calls), n))
