@@ -544,8 +544,8 @@ def config_c5(job):
                                                            "inside jea_decode_batch the pass stores one 4-byte record per block plus the chunks "
                                                            "that hold a non-zero AC coefficient, far fewer bytes, so the equivalent rate may exceed "
                                                            "the HBM peak; bound by the latency of the serial walks, not by memory"},
-                    "decode_sync_kernel x2": {"us": round(ph[1] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes)},
-                    "unstuff kernels": {"us": round(ph[0] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes)}}}
+                    "decode_sync_kernel x2": {"us": round(ph[1] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes),
+                                              "note": "the stuffed bytes are dropped while the raw scan is staged: no unstuffing pass"}}}
     cpu = None
     if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
         t0 = time.perf_counter()
