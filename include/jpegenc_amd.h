@@ -97,6 +97,19 @@ int jea_last_phase_ms(jea_ctx* ctx, float* ms, size_t capacity, size_t* n_phases
 #define JEA_MAPPER_RGB 1
 int jea_set_colour_mapper(jea_ctx* ctx, int mapper);
 
+/* Per-image Huffman tables (default off).  The reference writes the Annex K tables into every file and names
+ * tailored ones as future work ("implement frequency analysis to generate tailored Huffman tables - requires
+ * two passes in encoder", entropy_encoder.cpp:614; the header writer's note at :637-638 says the same).  With
+ * on != 0 jea_encode_batch[_async] and jea_encode_host make that second pass: symbols are counted per image,
+ * each of the four tables gets the code lengths of a Huffman tree over (count + 1) for every symbol of its
+ * alphabet -- so each table keeps all its symbols and the header keeps its 607 bytes and its layout -- limited to
+ * 16 bits as in T.81 K.3, and the DHT segment carries these tables.  jea_decode_batch and jea_decode_host then
+ * read the tables from each file's header instead of assuming the Annex K ones (the reference's decoder skips
+ * the segment, encoder.cpp:240).  Files are smaller (a smooth 512x512 picture at q=50: 6393 instead of 10570
+ * bytes) and decode to the same pixels.  Not available through the stripe, static-scratch, scan-only and
+ * per-block entry points, which keep the Annex K tables (the first two refuse the mode). */
+int jea_set_huffman_optimised(jea_ctx* ctx, int on);
+
 /* Quality -> tables, the arithmetic of Quantiser::Quantiser (quantiser.cpp:3-55). */
 void jea_quant_tables(int quality, uint16_t lum_q[64], uint16_t chr_q[64]);
 /* The fixed 607-byte header of encoder.cpp:74-138 (+ quantiser.cpp:87-102,

@@ -13,7 +13,7 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "HIP", 3: "CAPACITY", 4: "RANGE", 5: "BAD_HEAD
 
 EXPORTS = [
     "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_set_colour_mapper", "jea_get_stream", "jea_synchronize",
-    "jea_set_profiling", "jea_last_phase_ms", "jea_set_scratch_budget",
+    "jea_set_profiling", "jea_last_phase_ms", "jea_set_scratch_budget", "jea_set_huffman_optimised",
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_encode_batch_static_async", "jea_static_scratch_needed",
@@ -55,6 +55,7 @@ def load_library():
     lib.jea_last_error.restype = c.c_char_p
     lib.jea_set_stream.argtypes = [vp, vp]
     lib.jea_set_colour_mapper.argtypes = [vp, i32]
+    lib.jea_set_huffman_optimised.argtypes = [vp, i32]
     lib.jea_get_stream.argtypes = [vp]
     lib.jea_get_stream.restype = vp
     lib.jea_synchronize.argtypes = [vp]
@@ -232,6 +233,10 @@ class Context:
     def set_colour_mapper(self, mapper):
         """0: RGB -> YCbCr (default); 1: RGB pass-through, all components on the luminance tables."""
         self._check(self.lib.jea_set_colour_mapper(self.handle, int(mapper)))
+
+    def set_huffman_optimised(self, on):
+        """Per-image Huffman tables in encode_batch / encode_host, read back from the files by decode_batch / decode_host."""
+        self._check(self.lib.jea_set_huffman_optimised(self.handle, 1 if on else 0))
 
     # ---- stages ----
     def fdct_quant(self, d_rgb, n_images, w, h, lum, chrom):

@@ -71,6 +71,7 @@ struct jea_ctx {
     StepTables* d_steps = nullptr;
     int32_t* d_status = nullptr;
     ComponentMode mode;   // jea_set_colour_mapper
+    bool optimal_huffman = false;   // jea_set_huffman_optimised
     unsigned char* static_scratch = nullptr;   // this GPU's copy of `scratch`
     // jea_set_profiling: events recorded at the phase boundaries of the last encode / decode call
     size_t scratch_budget = (size_t)32 << 30;   // jea_set_scratch_budget
@@ -83,7 +84,8 @@ struct jea_ctx {
     DeviceBuffer stream_copy, small;  // jea_stream_upload / per-block entry points
     // parallel decode
     DeviceBuffer ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
-        round_flags, grp_pending, grp_end, sub_guess, first_bad, ctx_keys, ctx_vals;
+        round_flags, grp_pending, grp_end, sub_guess, first_bad, ctx_keys, ctx_vals, huff_hist, huff_tables, huff_spec,
+        step_tables;
     DeviceBuffer tile_ff8;
     void* pin_io = nullptr;   // pinned staging for the host-buffer entry points
     size_t pin_io_bytes = 0;
@@ -525,6 +527,7 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->ustream, &ctx->chunk_drops, &ctx->chunk_base, &ctx->img_drops,
                             &ctx->sub_end, &ctx->sub_used, &ctx->sub_info, &ctx->grp_sum, &ctx->grp_base,
                             &ctx->round_flags, &ctx->grp_pending, &ctx->grp_end, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
+                            &ctx->huff_hist, &ctx->huff_tables, &ctx->huff_spec, &ctx->step_tables,
                             &ctx->ctx_vals, &ctx->tile_ff8})
         free_buffer(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -558,6 +561,12 @@ int jea_set_colour_mapper(jea_ctx* ctx, int mapper) {
     if (mapper == JEA_MAPPER_YCBCR) ctx->mode = ComponentMode{1u, 0u};
     else if (mapper == JEA_MAPPER_RGB) ctx->mode = ComponentMode{7u, 1u};
     else return fail(ctx, JEA_ERR_INVALID_ARG, "jea_set_colour_mapper: unknown mapper");
+    return JEA_OK;
+}
+
+int jea_set_huffman_optimised(jea_ctx* ctx, int on) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    ctx->optimal_huffman = on != 0;
     return JEA_OK;
 }
 
@@ -959,6 +968,14 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
     // scratch first: growing a buffer synchronises the stream, which must not happen between the launches
     EntropyScratch sc;
     if ((rc = prepare_entropy_scratch(ctx, pass, mcus, out_capacity, sc))) return rc;
+    if (ctx->optimal_huffman) {
+        if ((rc = ensure(ctx, ctx->huff_hist, pass * 1024 * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->huff_tables, pass * sizeof(HuffTables)))) return rc;
+        if ((rc = ensure(ctx, ctx->huff_spec, pass * kHuffSpecBytes))) return rc;
+        sc.optimal.hist = (uint32_t*)ctx->huff_hist.ptr;
+        sc.optimal.tables = (HuffTables*)ctx->huff_tables.ptr;
+        sc.optimal.spec = (uint8_t*)ctx->huff_spec.ptr;
+    }
     const size_t image_bytes = (size_t)3 * width * height;
     for (size_t first = 0; first < n_images; first += pass) {
         const size_t n = n_images - first < pass ? n_images - first : pass;
@@ -982,6 +999,8 @@ int jea_encode_batch_static_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_i
     if (!ctx) return JEA_ERR_INVALID_ARG;
     if (!encode_args_ok(d_rgb, n_images, width, height, lum_q, chr_q, d_out, out_capacity, d_offsets, d_sizes, d_status))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch_static_async: invalid argument");
+    if (ctx->optimal_huffman)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_batch_static_async: per-image Huffman tables are not available here; use jea_encode_batch_async");
     const size_t mcus = mcus_of(width, height);
     const StaticLayout l = static_layout(n_images, mcus);
     if (l.total > kStaticScratchBytes)
@@ -1056,6 +1075,8 @@ int jea_stripe_transform(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t wid
     if (!ctx) return JEA_ERR_INVALID_ARG;
     if (!d_rgb_stripe || !last_dc || !valid_dims(width, stripe_height) || !tables_ok(lum_q, chr_q))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_transform: invalid argument");
+    if (ctx->optimal_huffman)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_transform: per-image Huffman tables are not available for stripes");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
     const size_t mcus = mcus_of(width, stripe_height);
     int rc;

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t
                                                                 uint32_t* __restrict__ slots,
                                                                 uint32_t* __restrict__ tile_bits,
                                                                 uint4* __restrict__ tile_ff8,
-                                                                int32_t* __restrict__ status) {
+                                                                int32_t* __restrict__ status, uint32_t tables_per_image) {
     __shared__ HuffLds h;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t count[8];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t
             prev_dc = (b >= 3) ? (int)p[-192] : 0;
         }
     }
-    load_huff<kEntThreads>(h, huff);
+    load_huff<kEntThreads>(h, huff + (tables_per_image ? blockIdx.y : 0u));
     if (threadIdx.x < 8) count[threadIdx.x] = 0;
     __syncthreads();
 
@@ -803,6 +803,174 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
     }
 }
 
+// ---------------------------------------------------------------------------
+// Per-image Huffman tables: symbol counts, then the tables, then (after the files are written) the table
+// bytes into the headers.  The procedure is this build's own (the reference has none) and is stated once, in
+// the CPU restatement's jo_optimal_table; what follows computes the same, step for step.
+// ---------------------------------------------------------------------------
+
+template <bool kPlanar>
+__global__ __launch_bounds__(kEntThreads) void symbol_histogram_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+                                                                       const uint8_t* __restrict__ chunk_masks,
+                                                                       ComponentMode mode, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[2 * 512];   // [class][DC symbols at 0, AC symbols at 256]
+    const uint32_t tile = blockIdx.x, img = blockIdx.y;
+    for (uint32_t i = threadIdx.x; i < 1024; i += kEntThreads) h[i] = 0;
+    const uint32_t b = tile * kTileBlocks + threadIdx.x;
+    const bool has_block = threadIdx.x < kTileBlocks && b < nbc;
+    BlockRegs blk;
+    const int ch = (int)(b % 3u);
+    int prev_dc = 0;
+    if (has_block) {
+        if (kPlanar) {
+            const uint32_t n_mcu = nbc / 3u, mcu = b / 3u;
+            const uint4* q = reinterpret_cast<const uint4*>(coefs) + ((size_t)img * 24 + ch) * n_mcu + mcu;
+            load_block_planar(blk, q, (size_t)3 * n_mcu, (uint32_t)chunk_masks[(size_t)img * nbc + b]);
+            prev_dc = (b >= 3) ? (int)*reinterpret_cast<const int16_t*>(q - 1) : 0;
+        } else {
+            const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
+            load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
+            prev_dc = (b >= 3) ? (int)p[-192] : 0;
+        }
+    }
+    __syncthreads();
+    if (has_block) {
+        HistSink sink;
+        sink.hist = h + (mode.is_lum((uint32_t)ch) ? 0 : 512);
+        // the code tables only shape the bits, which this sink throws away: any readable words will do
+        (void)encode_block(blk, prev_dc, h, h, sink);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 1024; i += kEntThreads)
+        if (h[i] != 0) atomicAdd(&hist[(size_t)img * 1024 + i], h[i]);
+}
+
+// id of an AC symbol in the ascending list of the 162 symbols the format has (sizes 1..10 with runs 0..15, the
+// end-of-block symbol 0x00 and the run symbol 0xF0); -1 for the others.
+__device__ __forceinline__ int ac_symbol_id(uint32_t s) {
+    const uint32_t run = s >> 4, ss = s & 15u;
+    if (s == 0x00u) return 0;
+    if (s == 0xF0u) return 151;
+    if (ss < 1u || ss > 10u) return -1;
+    return (int)(1u + run * 10u + (ss - 1u) + (run == 15u ? 1u : 0u));
+}
+
+// One wave per table: blockIdx.x = table in header order (lum DC, lum AC, chr DC, chr AC), blockIdx.y = image.
+__global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __restrict__ hist, HuffTables* __restrict__ tables,
+                                                           uint8_t* __restrict__ spec) {
+    constexpr int kMax = 163;
+    __shared__ unsigned long long key[kMax + 1];
+    __shared__ unsigned long long weight[2 * kMax];
+    __shared__ uint16_t parent[2 * kMax];
+    __shared__ uint16_t order[kMax + 1];
+    __shared__ uint8_t syms[kMax];
+    __shared__ uint32_t count[2 * kMax + 2];
+    __shared__ uint16_t leaf_depth[kMax + 1];
+    __shared__ uint8_t vals[kMax];
+    const uint32_t t = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    const bool is_ac = (t & 1u) != 0;
+    const uint32_t cls = t >> 1;
+    const int n = is_ac ? 162 : 12, N = n + 1;
+    const uint32_t* freq = hist + ((size_t)img * 4 + t) * 256;
+    // 1. leaves: weight = occurrences + 1, and the extra leaf of weight 0; key ascending = (weight, id descending)
+    for (uint32_t s = lane; s < 256; s += 64) {
+        const int id = is_ac ? ac_symbol_id(s) : (s < 12u ? (int)s : -1);
+        if (id >= 0) {
+            syms[id] = (uint8_t)s;
+            key[id] = ((unsigned long long)freq[s] + 1ull) << 9 | (unsigned long long)(511 - id);
+        }
+    }
+    if (lane == 0) key[n] = (unsigned long long)(511 - n);
+    for (uint32_t i = lane; i < 2 * kMax + 2; i += 64) count[i] = 0;
+    __syncthreads();
+    // 2. sort by counting smaller keys (the keys are distinct)
+    for (int i = (int)lane; i < N; i += 64) {
+        const unsigned long long k = key[i];
+        int rank = 0;
+        for (int j = 0; j < N; ++j) rank += key[j] < k ? 1 : 0;
+        order[rank] = (uint16_t)i;
+        weight[rank] = k >> 9;
+    }
+    __syncthreads();
+    // two queues: leaves in sorted order (nodes 0..N-1), merged nodes in creation order (N..2N-2); the lighter head
+    // is taken, the leaf on a tie
+    if (lane == 0) {
+        int lh = 0, ih = N, made = N;
+        for (int m = 0; m < N - 1; ++m) {
+            int pick[2];
+            for (int k = 0; k < 2; ++k) {
+                if (lh < N && (ih >= made || weight[lh] <= weight[ih])) pick[k] = lh++;
+                else pick[k] = ih++;
+            }
+            weight[made] = weight[pick[0]] + weight[pick[1]];
+            parent[pick[0]] = parent[pick[1]] = (uint16_t)made;
+            ++made;
+        }
+    }
+    __syncthreads();
+    // 3. depth of every leaf = steps up to the root, node 2N-2
+    for (int i = (int)lane; i < N; i += 64) {
+        int v = i, d = 0;
+        while (v != 2 * N - 2) {
+            v = parent[v];
+            ++d;
+        }
+        leaf_depth[order[i]] = (uint16_t)d;
+        atomicAdd(&count[d], 1u);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = 2 * kMax; i > 16; --i) {   // T.81 Figure K.3
+            while (count[i] > 0) {
+                int j = i - 2;
+                while (count[j] == 0) --j;
+                count[i] -= 2;
+                count[i - 1] += 1;
+                count[j + 1] += 2;
+                count[j] -= 1;
+            }
+        }
+        int i = 16;
+        while (count[i] == 0) --i;
+        count[i]--;                             // the extra leaf
+    }
+    // 4. symbols by (depth, id): the value list
+    for (int i = (int)lane; i < n; i += 64) {
+        const uint32_t k = (uint32_t)leaf_depth[i] << 8 | (uint32_t)i;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += ((uint32_t)leaf_depth[j] << 8 | (uint32_t)j) < k ? 1 : 0;
+        vals[rank] = syms[i];
+    }
+    __syncthreads();
+    // the table as the header carries it, and the code words (T.81 Annex C)
+    const uint32_t at = (t == 0 ? 0u : (t == 1 ? 29u : (t == 2 ? 208u : 237u)));
+    uint8_t* out = spec + (size_t)img * kHuffSpecBytes + at;
+    uint32_t* codes = is_ac ? tables[img].ac[cls] : tables[img].dc[cls];
+    if (is_ac)
+        for (uint32_t s = lane; s < 256; s += 64) codes[s] = 0;
+    __syncthreads();
+    if (lane == 0) out[0] = (uint8_t)((is_ac ? 0x10u : 0x00u) | cls);
+    if (lane < 16) out[1 + lane] = (uint8_t)count[1 + lane];
+    for (int i = (int)lane; i < n; i += 64) out[17 + i] = vals[i];
+    if (lane == 0) {
+        uint32_t code = 0;
+        int k = 0;
+        for (uint32_t l = 1; l <= 16; ++l) {
+            for (uint32_t i = 0; i < count[l]; ++i, ++k) codes[vals[k]] = code++ | (l << 16);
+            code <<= 1;
+        }
+    }
+}
+
+// The tables' bytes into the header of every file (the files have been written with the standard header).
+__global__ void patch_huffman_spec_kernel(uint8_t* __restrict__ out, const uint64_t* __restrict__ offsets,
+                                          const uint8_t* __restrict__ spec, const int32_t* __restrict__ status) {
+    if (*status != 0) return;
+    uint8_t* file = out + offsets[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < kHuffSpecBytes; i += blockDim.x)
+        file[kHuffSpecOffset + i] = spec[(size_t)blockIdx.x * kHuffSpecBytes + i];
+}
+
 }  // namespace
 
 void launch_bit_lengths(hipStream_t s, const int16_t* d_coefs, size_t n_images, size_t mcus_per_image,
@@ -825,15 +993,26 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     const uint32_t n = (uint32_t)n_images;
     const uint32_t eoi = with_eoi ? 1u : 0u;
 
+    const bool optimal = sc.optimal.tables != nullptr;
+    if (optimal) {
+        // two passes over the coefficients, as the reference's note says: count the symbols, make the tables
+        (void)hipMemsetAsync(sc.optimal.hist, 0, n_images * 1024 * sizeof(uint32_t), s);
+        if (sc.planar)
+            symbol_histogram_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, sc.chunk_masks, sc.mode, sc.optimal.hist);
+        else
+            symbol_histogram_kernel<false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, sc.chunk_masks, sc.mode, sc.optimal.hist);
+        build_huffman_kernel<<<dim3(4, n), 64, 0, s>>>(sc.optimal.hist, sc.optimal.tables, sc.optimal.spec);
+        d_huff = sc.optimal.tables;
+    }
     // The bit-length kernel also tallies the 0xFF bytes; one kernel packs and stuffs.
     if (sc.planar)
         tile_bits_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.chunk_masks, sc.mode,
                                                             sc.len16, sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8,
-                                                            d_status);
+                                                            d_status, optimal ? 1u : 0u);
     else
         tile_bits_kernel<false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.chunk_masks, sc.mode,
                                                              sc.len16, sc.slots, sc.tile_bits, (uint4*)sc.tile_ff8,
-                                                             d_status);
+                                                             d_status, optimal ? 1u : 0u);
     if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[0], s);
     if (n == 1 && n_tiles <= kFoldTiles && d_prev_offset == nullptr) {
         // One image with few tiles: every workgroup sums over the tiles before it, which is cheaper than a
@@ -842,6 +1021,7 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
                                                              (const uint4*)sc.tile_ff8, nullptr, nullptr, d_offsets,
                                                              d_sizes, header, (uint32_t)header_len, eoi, d_out,
                                                              out_capacity, d_status);
+        if (optimal && header_len) patch_huffman_spec_kernel<<<n, 256, 0, s>>>(d_out, d_offsets, sc.optimal.spec, d_status);
         return;
     }
     ImageLevel lvl{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
@@ -854,6 +1034,7 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
                                                           (const uint4*)sc.tile_ff8, sc.tile_base, sc.tile_ffbase,
                                                           d_offsets, d_sizes, header, (uint32_t)header_len, eoi, d_out,
                                                           out_capacity, d_status);
+    if (optimal && header_len) patch_huffman_spec_kernel<<<n, 256, 0, s>>>(d_out, d_offsets, sc.optimal.spec, d_status);
 }
 
 namespace {

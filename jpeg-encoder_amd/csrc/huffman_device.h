@@ -72,6 +72,8 @@ __device__ __forceinline__ uint32_t bit_width(uint32_t v) { return 32u - (uint32
 //       low SSSS bits of diff (diff > 0) or of ~|diff| (diff <= 0)
 //   AC  :101-118: (run, v) on every non-zero v, (15, 0) for each full run of 16
 //       zeros that is followed by a non-zero; EOB iff zz[63] == 0;  :732-765 codes
+// Sink::symbol(is_ac, symbol) is told every symbol before its bits (the histogram pass of the
+// per-image tables listens; the other sinks ignore it).
 // Returns false when a value falls outside the tables (SSSS > 11 / > 10).
 template <class Sink>
 __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, const uint32_t* __restrict__ dc_tab,
@@ -84,6 +86,7 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
         if (s > 11) { ok = false; s = 11; }
         const uint32_t e = dc_tab[s];
         const uint32_t extra = (diff > 0 ? amp : ~amp) & ((1u << s) - 1u);
+        sink.symbol(false, s);
         sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
     }
     uint32_t run = 0;
@@ -105,6 +108,7 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
             if (v != 0) {
                 while (run >= 16) {
                     const uint32_t z = ac_tab[0xF0];
+                    sink.symbol(true, 0xF0u);
                     sink.put(z & 0xffffu, z >> 16);
                     run -= 16;
                 }
@@ -115,6 +119,7 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
                 const uint32_t e = ac_tab[(run << 4) | s];
                 // the low s bits of v (v > 0) or of v - 1 (v < 0), entropy_encoder.cpp:745-765
                 const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)(v + (v >> 31)), 0u, s);
+                sink.symbol(true, (run << 4) | s);
                 sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
                 run = 0;
             } else {
@@ -125,6 +130,7 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
     if (largest > 1023u) ok = false;
     if (run > 0) {  // zz[63] == 0: trailing zeros (and their ZRLs) collapse into EOB
         const uint32_t e = ac_tab[0x00];
+        sink.symbol(true, 0x00u);
         sink.put(e & 0xffffu, e >> 16);
     }
     return ok;
@@ -133,6 +139,15 @@ __device__ __forceinline__ bool encode_block(const BlockRegs& blk, int prev_dc, 
 struct CountSink {
     uint32_t bits = 0;
     __device__ __forceinline__ void put(uint32_t, uint32_t n) { bits += n; }
+    __device__ __forceinline__ void symbol(bool, uint32_t) {}
+    __device__ __forceinline__ void finish() {}
+};
+
+// Counts symbols: hist[symbol] for DC symbols, hist[256 + symbol] for AC symbols (LDS, shared by the workgroup).
+struct HistSink {
+    uint32_t* hist;
+    __device__ __forceinline__ void put(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void symbol(bool is_ac, uint32_t sym) { atomicAdd(&hist[(is_ac ? 256u : 0u) + sym], 1u); }
     __device__ __forceinline__ void finish() {}
 };
 
@@ -155,6 +170,7 @@ struct SlotSink {
             nacc -= 32;
         }
     }
+    __device__ __forceinline__ void symbol(bool, uint32_t) {}
     __device__ __forceinline__ void finish() {
         if (nacc > 0) *slot = (uint32_t)(acc >> 32);
     }

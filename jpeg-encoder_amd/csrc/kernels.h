@@ -130,6 +130,16 @@ struct StripeInfo {
 
 // Device-side bookkeeping of one encode pass; all arrays are caller-provided
 // scratch.  n_tiles = tiles per image, n = images.
+// Per-image Huffman tables (the optional mode the reference names as future work, entropy_encoder.cpp:614):
+// scratch of launch_entropy_encode's two extra kernels.  All null: the Annex K tables for every image.
+constexpr uint32_t kHuffSpecBytes = 416;    // four tables as the header carries them: id byte, 16 counts, values
+constexpr uint32_t kHuffSpecOffset = 177;   // where they sit in the 607-byte header
+struct OptimalHuffman {
+    uint32_t* hist = nullptr;      // [n][4][256] symbol counts in header order: lum DC, lum AC, chr DC, chr AC
+    HuffTables* tables = nullptr;  // [n] code words of image i
+    uint8_t* spec = nullptr;       // [n][kHuffSpecBytes]
+};
+
 struct EntropyScratch {
     uint16_t* len16;        // [n][mcus*3]      bits per block-channel
     const uint8_t* chunk_masks;  // [n][mcus*3] non-zero 16-byte chunks of each block, or null = load everything
@@ -149,6 +159,7 @@ struct EntropyScratch {
                             // alignments it may get, as 16-bit counts
     hipEvent_t* marks = nullptr;   // timing marks (null = none): launch_entropy_encode records marks[0] after the
                                    // bit-string kernel; the caller records what comes before and after
+    OptimalHuffman optimal;
 };
 
 // d_status_to_clear (may be null): status word of the encode pass this launch opens; the kernel zeroes it.

@@ -184,13 +184,37 @@ static void jo_build_hufftab(jo_hufftab* t, const uint8_t bits[16], const uint8_
         code <<= 1;
     }
 }
+/* The tables in use, in the form the header carries them (entropy_encoder.cpp:672-693): for each of the four
+ * tables in header order -- lum DC, lum AC, chr DC, chr AC -- the class/id byte, 16 counts, the values: 29, 179,
+ * 29 and 179 bytes.  The reference only ever has the Annex K tables (JO_SPEC_STD); the optimised-table mode
+ * below (which the reference names as future work, entropy_encoder.cpp:614) switches the spec for one file. */
+#define JO_SPEC_BYTES 416
+static uint8_t JO_SPEC[JO_SPEC_BYTES];
+static int jo_spec_ready = 0;
+static int jo_dlut_ready;
+static void jo_spec_std(uint8_t* o) {
+    size_t p = 0;
+    o[p++] = 0x00; memcpy(o + p, JO_DC_LUM_BITS, 16); p += 16; memcpy(o + p, JO_DC_VALS, 12); p += 12;
+    o[p++] = 0x10; memcpy(o + p, JO_AC_LUM_BITS, 16); p += 16; memcpy(o + p, JO_AC_LUM_VALS, 162); p += 162;
+    o[p++] = 0x01; memcpy(o + p, JO_DC_CHR_BITS, 16); p += 16; memcpy(o + p, JO_DC_VALS, 12); p += 12;
+    o[p++] = 0x11; memcpy(o + p, JO_AC_CHR_BITS, 16); p += 16; memcpy(o + p, JO_AC_CHR_VALS, 162); p += 162;
+}
+static const size_t JO_SPEC_AT[4] = {0, 29, 208, 237};   /* lum DC, lum AC, chr DC, chr AC */
 static void jo_init_huff(void) {
     if (jo_ht_ready) return;
-    jo_build_hufftab(&JO_HT[0][0], JO_DC_LUM_BITS, JO_DC_VALS);
-    jo_build_hufftab(&JO_HT[0][1], JO_AC_LUM_BITS, JO_AC_LUM_VALS);
-    jo_build_hufftab(&JO_HT[1][0], JO_DC_CHR_BITS, JO_DC_VALS);
-    jo_build_hufftab(&JO_HT[1][1], JO_AC_CHR_BITS, JO_AC_CHR_VALS);
+    if (!jo_spec_ready) { jo_spec_std(JO_SPEC); jo_spec_ready = 1; }
+    jo_build_hufftab(&JO_HT[0][0], JO_SPEC + JO_SPEC_AT[0] + 1, JO_SPEC + JO_SPEC_AT[0] + 17);
+    jo_build_hufftab(&JO_HT[0][1], JO_SPEC + JO_SPEC_AT[1] + 1, JO_SPEC + JO_SPEC_AT[1] + 17);
+    jo_build_hufftab(&JO_HT[1][0], JO_SPEC + JO_SPEC_AT[2] + 1, JO_SPEC + JO_SPEC_AT[2] + 17);
+    jo_build_hufftab(&JO_HT[1][1], JO_SPEC + JO_SPEC_AT[3] + 1, JO_SPEC + JO_SPEC_AT[3] + 17);
     jo_ht_ready = 1;
+}
+/* spec = NULL: back to the Annex K tables.  Not thread safe (like jo_set_mapper). */
+void jo_use_huffman_spec(const uint8_t* spec) {
+    if (spec) memcpy(JO_SPEC, spec, JO_SPEC_BYTES); else jo_spec_std(JO_SPEC);
+    jo_spec_ready = 1;
+    jo_ht_ready = 0;
+    jo_dlut_ready = 0;
 }
 
 /* Exports the four code tables: code[4][256] / len[4][256] in the order
@@ -407,6 +431,7 @@ static int jo_bit_width(unsigned v) { int n = 0; while (v) { ++n; v >>= 1; } ret
 /* Number of bits one block-channel contributes, and (optionally) the bits
  * themselves.  entropy_encoder.cpp:94-120 (run-length pass incl. the trailing
  * ZRL removal), :715-730 (DC), :732-765 (AC).  zz is in zigzag order. */
+static uint32_t* jo_hist = NULL;   /* [2 classes][2: DC, AC][256] symbol counts, filled while non-NULL */
 static int jo_encode_block(const int16_t zz[64], int16_t* last_dc, int is_lum, jo_bw* w, uint32_t* nbits_out) {
     jo_init_huff();
     const jo_hufftab* dc = &JO_HT[is_lum ? 0 : 1][0];
@@ -417,6 +442,7 @@ static int jo_encode_block(const int16_t zz[64], int16_t* last_dc, int is_lum, j
     unsigned amp = (unsigned)(diff > 0 ? diff : -diff);
     int ssss = jo_bit_width(amp);
     if (ssss > 11) return JO_ERR_RANGE;
+    if (jo_hist) jo_hist[((is_lum ? 0 : 1) * 2 + 0) * 256 + ssss]++;
     if (w) jo_bw_put(w, dc->code[ssss], dc->len[ssss]);
     nbits += dc->len[ssss];
     if (ssss > 0) {
@@ -446,6 +472,7 @@ static int jo_encode_block(const int16_t zz[64], int16_t* last_dc, int is_lum, j
             if (s > 10) return JO_ERR_RANGE;
             sym = (unsigned)(runs[i] << 4) | (unsigned)s;
         }
+        if (jo_hist) jo_hist[((is_lum ? 0 : 1) * 2 + 1) * 256 + sym]++;
         if (w) jo_bw_put(w, ac->code[sym], ac->len[sym]);
         nbits += ac->len[sym];
         if (s > 0) {
@@ -542,18 +569,8 @@ size_t jo_write_header(uint8_t out[JO_HEADER_BYTES], int w, int h, const uint16_
     p = jo_put8(out, p, 3); p = jo_put8(out, p, 0x11); p = jo_put8(out, p, 1);
     p = jo_put16(out, p, 0xFFC4);                                       /* DHT */
     p = jo_put16(out, p, 2 + 4 * 17 + 12 + 12 + 162 + 162);
-    p = jo_put8(out, p, 0x00);
-    for (int i = 0; i < 16; ++i) p = jo_put8(out, p, JO_DC_LUM_BITS[i]);
-    for (int i = 0; i < 12; ++i) p = jo_put8(out, p, JO_DC_VALS[i]);
-    p = jo_put8(out, p, 0x10);
-    for (int i = 0; i < 16; ++i) p = jo_put8(out, p, JO_AC_LUM_BITS[i]);
-    for (int i = 0; i < 162; ++i) p = jo_put8(out, p, JO_AC_LUM_VALS[i]);
-    p = jo_put8(out, p, 0x01);
-    for (int i = 0; i < 16; ++i) p = jo_put8(out, p, JO_DC_CHR_BITS[i]);
-    for (int i = 0; i < 12; ++i) p = jo_put8(out, p, JO_DC_VALS[i]);
-    p = jo_put8(out, p, 0x11);
-    for (int i = 0; i < 16; ++i) p = jo_put8(out, p, JO_AC_CHR_BITS[i]);
-    for (int i = 0; i < 162; ++i) p = jo_put8(out, p, JO_AC_CHR_VALS[i]);
+    jo_init_huff();
+    for (int i = 0; i < JO_SPEC_BYTES; ++i) p = jo_put8(out, p, JO_SPEC[i]);
     p = jo_put16(out, p, 0xFFDA); p = jo_put16(out, p, 12);            /* SOS */
     p = jo_put8(out, p, 3);
     p = jo_put8(out, p, 1); p = jo_put8(out, p, 0x00);
@@ -584,6 +601,140 @@ int jo_encode(const uint8_t* rgb, int w, int h, int quality, uint8_t* out, size_
     size_t p = jo_write_header(out, w, h, lumq, chrq);
     size_t scan_len = 0;
     rc = jo_coefs_to_scan(coefs, n_mcu, out + p, cap - p - 2, &scan_len, NULL);
+    free(coefs);
+    if (rc) return rc;
+    p += scan_len;
+    p = jo_put16(out, p, 0xFFD9);
+    *out_len = p;
+    return JO_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Per-image Huffman tables.  The reference has none ("Issue: implement        */
+/* frequency analysis to generate tailored Huffman tables - requires two       */
+/* passes in encoder", entropy_encoder.cpp:614); this is the specification of  */
+/* this build's optional mode, which the GPU code must reproduce bit for bit.  */
+/* Parity unpinned: nothing of the reference covers it; the files are checked  */
+/* against an independent JPEG decoder by the tests.                           */
+/*                                                                             */
+/* For each of the four tables, over its symbol set (DC: 0..11; AC: the 162    */
+/* symbols of the Annex K lists) in ascending symbol value, id = 0..n-1:       */
+/*  1. weight = occurrences + 1 (every symbol keeps a code, so the header      */
+/*     keeps its 607 bytes and its layout); one more leaf, id n, weight 0: it  */
+/*     ends up with the longest code and keeps the all-ones code word unused   */
+/*     (T.81 K.2 does the same with symbol 256).                               */
+/*  2. leaves sorted by (weight, id descending); Huffman tree by the two-queue */
+/*     method: of the heads of the leaf queue and of the queue of merged       */
+/*     nodes (in creation order) the lighter one is taken, a leaf on a tie.    */
+/*  3. code length = depth; lengths above 16 are brought down as in T.81       */
+/*     Figure K.3; the extra leaf's count leaves the longest length in use.    */
+/*  4. symbols ordered by (depth, id) take the lengths in ascending order:     */
+/*     that order is the table's value list (T.81 Annex C gives the codes).    */
+/* ------------------------------------------------------------------------- */
+static int jo_sym_set(int is_ac, uint8_t* syms) {
+    int n = 0;
+    if (!is_ac) { for (int s = 0; s < 12; ++s) syms[n++] = (uint8_t)s; return n; }
+    for (int s = 0; s < 256; ++s) {
+        int ss = s & 15;
+        if ((ss >= 1 && ss <= 10) || s == 0x00 || s == 0xF0) syms[n++] = (uint8_t)s;
+    }
+    return n;   /* 162 */
+}
+
+static void jo_optimal_table(const uint32_t* freq /*[256]*/, int is_ac, uint8_t bits_out[16], uint8_t* vals_out) {
+    uint8_t syms[163];
+    const int n = jo_sym_set(is_ac, syms), N = n + 1;
+    uint64_t key[163];            /* weight << 9 | (511 - id): ascending = (weight, id descending) */
+    for (int i = 0; i < n; ++i) key[i] = ((uint64_t)freq[syms[i]] + 1) << 9 | (uint64_t)(511 - i);
+    key[n] = (uint64_t)(511 - n);
+    int order[163];               /* leaves by ascending key */
+    for (int i = 0; i < N; ++i) {
+        int rank = 0;
+        for (int j = 0; j < N; ++j) rank += key[j] < key[i];
+        order[rank] = i;
+    }
+    /* nodes 0..N-1: leaves in sorted order; N..2N-2: merged nodes in creation order */
+    uint64_t weight[2 * 163];
+    int parent[2 * 163];
+    for (int i = 0; i < N; ++i) weight[i] = key[order[i]] >> 9;
+    int lh = 0, ih = N, made = N;
+    for (int m = 0; m < N - 1; ++m) {
+        int pick[2];
+        for (int k = 0; k < 2; ++k) {
+            if (lh < N && (ih >= made || weight[lh] <= weight[ih])) pick[k] = lh++;
+            else pick[k] = ih++;
+        }
+        weight[made] = weight[pick[0]] + weight[pick[1]];
+        parent[pick[0]] = parent[pick[1]] = made;
+        ++made;
+    }
+    int depth[2 * 163];
+    depth[made - 1] = 0;
+    for (int v = made - 2; v >= 0; --v) depth[v] = depth[parent[v]] + 1;
+    int count[2 * 163 + 1];
+    memset(count, 0, sizeof(count));
+    int leaf_depth[163];          /* by id */
+    for (int i = 0; i < N; ++i) { leaf_depth[order[i]] = depth[i]; count[depth[i]]++; }
+    for (int i = 2 * 163; i > 16; --i) {      /* T.81 Figure K.3 */
+        while (count[i] > 0) {
+            int j = i - 2;
+            while (count[j] == 0) --j;
+            count[i] -= 2; count[i - 1] += 1; count[j + 1] += 2; count[j] -= 1;
+        }
+    }
+    { int i = 16; while (count[i] == 0) --i; count[i]--; }
+    for (int l = 1; l <= 16; ++l) bits_out[l - 1] = (uint8_t)count[l];
+    uint32_t skey[162];
+    for (int i = 0; i < n; ++i) skey[i] = (uint32_t)leaf_depth[i] << 8 | (uint32_t)i;
+    for (int i = 0; i < n; ++i) {
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += skey[j] < skey[i];
+        vals_out[rank] = syms[i];
+    }
+}
+
+/* The optimal tables of an image's coefficient blocks as a table spec (JO_SPEC_BYTES bytes). */
+int jo_optimal_huffman_spec(const int16_t* coefs, size_t n_mcu, uint8_t* spec) {
+    uint32_t* hist = (uint32_t*)calloc(4 * 256, sizeof(uint32_t));
+    if (!hist) return JO_ERR_CAPACITY;
+    int16_t last[3] = {0, 0, 0};
+    jo_hist = hist;
+    int rc = JO_OK;
+    for (size_t m = 0; m < n_mcu && !rc; ++m)
+        for (int ch = 0; ch < 3 && !rc; ++ch)
+            rc = jo_encode_block(coefs + (m * 3 + (size_t)ch) * 64, &last[ch], jo_is_lum(ch), NULL, NULL);
+    jo_hist = NULL;
+    if (!rc) {
+        static const uint8_t ids[4] = {0x00, 0x10, 0x01, 0x11};
+        for (int t = 0; t < 4; ++t) {
+            uint8_t* o = spec + JO_SPEC_AT[t];
+            o[0] = ids[t];
+            /* header order lum DC, lum AC, chr DC, chr AC; hist order [class][dc/ac] */
+            jo_optimal_table(hist + ((t >> 1) * 2 + (t & 1)) * 256, t & 1, o + 1, o + 17);
+        }
+    }
+    free(hist);
+    return rc;
+}
+
+/* jo_encode with the image's own optimal tables in the header and in the scan. */
+int jo_encode_optimised(const uint8_t* rgb, int w, int h, int quality, uint8_t* out, size_t cap, size_t* out_len) {
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return JO_ERR_RANGE;
+    if (cap < JO_HEADER_BYTES + 2) return JO_ERR_CAPACITY;
+    uint16_t lumq[64], chrq[64];
+    jo_quant_tables(quality, lumq, chrq);
+    size_t n_mcu = (size_t)((w + 7) / 8) * (size_t)((h + 7) / 8);
+    int16_t* coefs = (int16_t*)malloc(n_mcu * 3 * 64 * sizeof(int16_t));
+    if (!coefs) return JO_ERR_CAPACITY;
+    int rc = jo_image_to_coefs(rgb, w, h, lumq, chrq, coefs);
+    uint8_t spec[JO_SPEC_BYTES];
+    if (!rc) rc = jo_optimal_huffman_spec(coefs, n_mcu, spec);
+    if (rc) { free(coefs); return rc; }
+    jo_use_huffman_spec(spec);
+    size_t p = jo_write_header(out, w, h, lumq, chrq);
+    size_t scan_len = 0;
+    rc = jo_coefs_to_scan(coefs, n_mcu, out + p, cap - p - 2, &scan_len, NULL);
+    jo_use_huffman_spec(NULL);
     free(coefs);
     if (rc) return rc;
     p += scan_len;
@@ -689,7 +840,6 @@ static void jo_br_skip(jo_br* r, int n) {
 
 /* 16-bit prefix -> (length << 8) | symbol, 0 when no code word matches. */
 static uint16_t JO_DLUT[2][2][65536];
-static int jo_dlut_ready = 0;
 static void jo_init_dlut(void) {
     if (jo_dlut_ready) return;
     jo_init_huff();
@@ -849,6 +999,16 @@ int jo_decode(const uint8_t* jpeg, size_t len, int w, int h, int quality, uint8_
     }
     free(coefs);
     free(buf);
+    return rc;
+}
+
+/* jo_decode with the Huffman tables the file itself carries (files of jo_encode_optimised; the reference's
+ * decoder skips the DHT segment, encoder.cpp:240, and always uses its own tables). */
+int jo_decode_file_tables(const uint8_t* jpeg, size_t len, int w, int h, int quality, uint8_t* rgb) {
+    if (len < JO_HEADER_BYTES) return JO_ERR_BAD_HEADER;
+    jo_use_huffman_spec(jpeg + 177);
+    int rc = jo_decode(jpeg, len, w, h, quality, rgb);
+    jo_use_huffman_spec(NULL);
     return rc;
 }
 

@@ -36,6 +36,11 @@ def _load():
     lib.jo_gen_image.argtypes = [_int, _int, _int, _c.c_uint32, _vp]
     lib.jo_encode.argtypes = [_vp, _int, _int, _int, _vp, _sz, _c.POINTER(_sz)]
     lib.jo_decode.argtypes = [_vp, _sz, _int, _int, _int, _vp]
+    lib.jo_encode_optimised.argtypes = [_vp, _int, _int, _int, _vp, _sz, _c.POINTER(_sz)]
+    lib.jo_decode_file_tables.argtypes = [_vp, _sz, _int, _int, _int, _vp]
+    lib.jo_optimal_huffman_spec.argtypes = [_vp, _sz, _vp]
+    lib.jo_use_huffman_spec.argtypes = [_vp]
+    lib.jo_use_huffman_spec.restype = None
     lib.jo_quant_tables.argtypes = [_int, _vp, _vp]
     lib.jo_set_mapper.argtypes = [_int]
     lib.jo_set_mapper.restype = None
@@ -102,6 +107,29 @@ def encode(rgb, quality):
     if rc:
         raise RuntimeError("jo_encode rc=%d" % rc)
     return out[: n.value].tobytes()
+
+
+def encode_optimised(rgb, quality):
+    """The file with the image's own Huffman tables (this build's optional mode; the reference has none)."""
+    h, w = rgb.shape[:2]
+    rgb = np.ascontiguousarray(rgb)
+    cap = LIB.jo_max_jpeg_bytes(w, h)
+    out = np.zeros(cap, np.uint8)
+    n = _sz(0)
+    rc = LIB.jo_encode_optimised(_p(rgb), w, h, quality, _p(out), cap, _c.byref(n))
+    if rc:
+        raise RuntimeError("jo_encode_optimised rc=%d" % rc)
+    return out[: n.value].tobytes()
+
+
+def decode_file_tables(jpeg, w, h, quality):
+    """Decode with the Huffman tables in the file's header instead of the Annex K ones."""
+    buf = np.frombuffer(jpeg, np.uint8)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    rc = LIB.jo_decode_file_tables(_p(buf), buf.size, w, h, quality, _p(rgb))
+    if rc:
+        raise RuntimeError("jo_decode_file_tables rc=%d" % rc)
+    return rgb
 
 
 def set_mapper(mapper):
