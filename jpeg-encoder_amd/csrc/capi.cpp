@@ -336,7 +336,7 @@ bool build_step_table(const uint8_t bits[16], const uint8_t* vals, bool is_dc, u
     }
     for (uint32_t j = first_bucket; j < (1u << F); ++j) {
         const uint32_t offset = (uint32_t)offsetof(Table, slow) + (j - first_bucket) * kSub * 4u;
-        t.fast[j] = ((kSub - 1u) << 8) | (offset << 16);
+        t.fast[j] = ((16u + F) << 8) | (offset << 16);   // sub-tables of 2^(16 - F) entries: the index is the next 16 - F bits
     }
     return true;
 }
@@ -1215,8 +1215,12 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     if ((rc = ensure(ctx, ctx->ctx_vals, kContextSlots * sizeof(uint32_t)))) return rc;
     // the pinned block is this context's and the call ends with a wait: the copy may run behind the host;
     // a few images' worth goes as kernel arguments instead, which is quicker than the copy engine
+    // files with per-image Huffman tables: the tables are built from the headers first, which needs the scan
+    // offsets in device memory before the decoder's first kernel
+    const bool own_tables = ctx->optimal_huffman && with_headers;
+    if (own_tables && (rc = ensure(ctx, ctx->step_tables, n_images * sizeof(StepTables)))) return rc;
     DecodePrologue prologue;
-    if (3 * n_images <= kSeedWords) {
+    if (3 * n_images <= kSeedWords && !own_tables) {
         prologue.h_words = seg;
         prologue.n_words = (uint32_t)(3 * n_images);
     } else {
@@ -1263,6 +1267,13 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     sc.mode = ctx->mode;
     sc.grp_pending = (uint32_t*)ctx->grp_pending.ptr;
     sc.grp_end = (uint32_t*)ctx->grp_end.ptr;
+    sc.tables_per_image = own_tables;
+    const StepTables* step_tables = ctx->d_steps;
+    if (own_tables) {
+        launch_build_step_tables(ctx->stream, d_data, d_seg, n_images, JEA_HEADER_BYTES, (StepTables*)ctx->step_tables.ptr);
+        JEA_HIP(ctx, hipGetLastError());
+        step_tables = (const StepTables*)ctx->step_tables.ptr;
+    }
     sc.sub_guess = (uint32_t*)ctx->sub_guess.ptr;
     sc.first_bad = (uint32_t*)ctx->first_bad.ptr;
     sc.ctx_keys = (unsigned long long*)ctx->ctx_keys.ptr;
@@ -1276,18 +1287,18 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     // First without an unstuffed copy (the kernels read the raw scans).  A stream that two synchronisation rounds
     // do not settle -- exactly periodic ones, mostly -- goes through the variant with an unstuffing pass, which
     // has the repair rounds.
-    JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
+    JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, step_tables, d_coefs,
                                        ctx->d_status, follow_up, report, prologue, true));
     JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->profiling) ctx->n_marks = 5;   // unstuffing | synchronisation rounds | scan and write pass | follow-up
     if (with_headers && (rc = headers_ok())) return rc;
     if (report->unsettled != 0) {
         sc.marks = nullptr;
-        JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs,
+        JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, step_tables, d_coefs,
                                            ctx->d_status, follow_up, report, prologue, false));
         JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (report->unsettled != 0)
-            JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, ctx->d_steps, d_coefs, ctx->d_status,
+            JEA_HIP(ctx, repair_entropy_decode(ctx->stream, d_seg + n_images, plan, sc, step_tables, d_coefs, ctx->d_status,
                                                follow_up, report));
     }
     return report_status(ctx, report->status, what);

@@ -480,7 +480,8 @@ constexpr uint32_t kDcShift = 32 - StepTableDc::kFastBits, kAcShift = 32 - StepT
 // `tab`: the table to use (in LDS), v: the next 32 stream bits, shift: 32 - the table's fast bits.
 __device__ __forceinline__ uint32_t step_lookup(const uint8_t* tab, uint32_t v, uint32_t shift) {
     uint32_t e = *reinterpret_cast<const uint32_t*>(tab + ((v >> shift) << 2));
-    if ((e & 0xffu) == 0) e = *reinterpret_cast<const uint32_t*>(tab + (e >> 16) + (((v >> 16) & ((e >> 8) & 0xffu)) << 2));
+    // a longer code: the bits behind the index bits select the entry of a sub-table
+    if ((e & 0xffu) == 0) e = *reinterpret_cast<const uint32_t*>(tab + (e >> 16) + (((v << (32u - shift)) >> ((e >> 8) & 0xffu)) << 2));
     return e;
 }
 
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                const uint32_t* __restrict__ first_bad,
                                                                uint32_t lum_mask,
                                                                uint32_t* __restrict__ changed, RawSource raw,
-                                                               RawPrologue pro) {
+                                                               RawPrologue pro, uint32_t tables_per_image) {
     constexpr uint32_t kSubBits = 32 * W;
     constexpr uint32_t kGroupRaw = kOwned * 4 * W;
     __shared__ GroupWords<W> gw;
@@ -875,7 +876,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         if (tid == 0) ends[0] = 0;
     }
 
-    load_tables(t, tables);
+    load_tables(t, tables + (tables_per_image ? blockIdx.y : 0u));
     uint32_t limit = 0xffffffffu, n_active = kOwned;
     if (kRaw) {
         const RawGroup rg = stage_group_raw(gw, raw.scan + raw_offset, raw_len, (uint64_t)group * kGroupRaw,
@@ -1104,7 +1105,8 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const int4* __restrict__ grp_sum,
                                                                 const uint32_t* __restrict__ sub_end,
                                                                 const uint32_t* __restrict__ grp_pending,
-                                                                uint32_t* __restrict__ unsettled, RawSource raw) {
+                                                                uint32_t* __restrict__ unsettled, RawSource raw,
+                                                                uint32_t tables_per_image) {
     constexpr uint32_t kSubBits = 32 * W;
     constexpr uint32_t kGroupRaw = kOwned * 4 * W;
     __shared__ GroupWords<W, kWriteTail> gw;
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     // asked for first, so that they are under way while tables and stream are staged
     const int4 si = tid < kOwned ? sub_info[sub_index] : make_int4(0, 0, 0, 0);
     const uint32_t start_state = tid < kOwned ? sub_used[sub_index] : 0u;
-    load_tables(t, tables);
+    load_tables(t, tables + (tables_per_image ? blockIdx.y : 0u));
     const uint8_t* stream = kRaw ? nullptr : ustream + ubase[img];
     bool active;
     uint32_t limit = 0xffffffffu;
@@ -1260,6 +1262,165 @@ __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t* __res
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Step tables from a file's own DHT segment (files written with per-image Huffman tables): the device-side twin of
+// the host's build_step_table, one workgroup per image.  The segment is expected where this library's and the
+// reference's headers have it, with the alphabets' full sizes (12 and 162 values); anything else, or counts that
+// are no prefix code, or sub-tables that do not fit, yields tables in which nothing decodes, and the stream fails.
+// ---------------------------------------------------------------------------
+namespace {
+struct CanonicalCode {
+    int mincode[17], maxcode[17], valptr[17];   // per code length 1..16; maxcode = -1: no code of that length
+};
+
+// The code word that starts the 16-bit prefix p16, among lengths lmin..lmax: (length << 8) | symbol, or 0.
+__device__ __forceinline__ uint32_t canonical_decode(const CanonicalCode& cc, const uint8_t* vals, uint32_t p16, int lmin, int lmax) {
+    for (int l = lmin; l <= lmax; ++l) {
+        const int code = (int)(p16 >> (16 - l));
+        if (cc.maxcode[l] >= 0 && code <= cc.maxcode[l] && code >= cc.mincode[l])
+            return ((uint32_t)l << 8) | vals[cc.valptr[l] + code - cc.mincode[l]];
+    }
+    return 0;
+}
+
+// Entry of symbol `sym` with a code of l bits (build_step_table's rules).
+__device__ __forceinline__ uint32_t step_entry(uint32_t sym, uint32_t l, bool is_dc) {
+    const uint32_t ss = is_dc ? sym : (sym & 15u), run = is_dc ? 0u : (sym >> 4);
+    const bool valid = is_dc ? sym <= 11u : (ss <= 10u && (ss != 0u || sym == 0x00u || sym == 0xF0u));
+    if (!valid) return kStepBad | 1u;
+    uint32_t entry = (l + ss) | (run << 8) | (l << 16) | (((32u - ss) & 31u) << 24);
+    if (!is_dc && sym == 0x00u) entry |= kStepEndsBlock;
+    if (ss) entry |= kStepHasAmp | (is_dc ? kStepDcAdd : 0u);
+    return entry;
+}
+
+template <class Table>
+__device__ __forceinline__ void fill_step_table(Table& t, const CanonicalCode& cc, const uint8_t* bits, const uint8_t* vals,
+                                                bool is_dc, uint32_t eob_code, uint32_t eob_len, bool usable,
+                                                uint32_t* scan4) {
+    constexpr uint32_t F = Table::kFastBits;
+    const uint32_t tid = threadIdx.x, bad = kStepBad | 1u;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < (uint32_t)Table::kSlowEntries; i += kThreads) t.slow[i] = bad;
+    // the first index that leads to codes longer than the index: canonical codes grow with their length
+    uint32_t first_bucket = 1u << F;
+    if (usable)
+        for (int l = (int)F + 1; l <= 16; ++l)
+            if (bits[l - 1] != 0) {
+                first_bucket = (uint32_t)cc.mincode[l] >> (l - F);
+                break;
+            }
+    uint32_t carry = 0;   // sub-table entries handed out so far
+    bool overflow = false;
+    for (uint32_t j0 = 0; j0 < (1u << F); j0 += kThreads) {
+        const uint32_t j = j0 + tid;
+        uint32_t entry = bad, m = 0;
+        if (usable && j < first_bucket) {
+            const uint32_t d = canonical_decode(cc, vals, j << (16 - F), 1, (int)F);
+            if (d != 0) {
+                entry = step_entry(d & 0xffu, d >> 8, is_dc);
+                // the symbol, its amplitude bits and the end-of-block code all inside the index bits (kernels.h)
+                const uint32_t used = entry & 0xffu;
+                if (!(entry & (kStepBad | kStepEndsBlock)) && (is_dc || (entry & kStepHasAmp)) && eob_len >= 1 &&
+                    eob_len <= 7 && used + eob_len <= F && ((j >> (F - used - eob_len)) & ((1u << eob_len) - 1u)) == eob_code)
+                    entry = (entry + eob_len) | kStepEndsBlock | (eob_len << kStepEobLenShift);
+            }
+        } else if (usable) {
+            // longest code under this prefix = size of its sub-table
+            for (int l = (int)F + 1; l <= 16; ++l)
+                if (cc.maxcode[l] >= 0 && j >= ((uint32_t)cc.mincode[l] >> (l - F)) && j <= ((uint32_t)cc.maxcode[l] >> (l - F)))
+                    m = (uint32_t)l - F;
+        }
+        const uint32_t need = m ? 1u << m : 0u;
+        uint32_t incl = need;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(incl, d);
+            if (lane >= d) incl += u;
+        }
+        if (lane == 63) scan4[wave] = incl;
+        __syncthreads();
+        uint32_t at = carry + incl - need;
+        for (int w = 0; w < wave; ++w) at += scan4[w];
+        carry += scan4[0] + scan4[1] + scan4[2] + scan4[3];
+        __syncthreads();
+        if (m) {
+            if (at + need <= (uint32_t)Table::kSlowEntries) {
+                entry = ((32u - m) << 8) | (((uint32_t)offsetof(Table, slow) + at * 4u) << 16);
+                for (uint32_t k = 0; k < need; ++k) {
+                    const uint32_t d = canonical_decode(cc, vals, (j << (16 - F)) | (k << (16 - F - m)), (int)F + 1, (int)(F + m));
+                    t.slow[at + k] = d ? step_entry(d & 0xffu, d >> 8, is_dc) : bad;
+                }
+            } else {
+                overflow = true;
+            }
+        }
+        t.fast[j] = entry;
+    }
+    // sub-tables that do not fit: nothing of this table may decode
+    if (__syncthreads_or(overflow ? 1 : 0))
+        for (uint32_t j = tid; j < (1u << F); j += kThreads) t.fast[j] = bad;
+}
+
+__global__ __launch_bounds__(kThreads) void build_step_tables_kernel(const uint8_t* __restrict__ data,
+                                                                     const uint64_t* __restrict__ scan_offsets,
+                                                                     uint32_t header_bytes, uint32_t lum_mask_unused,
+                                                                     StepTables* __restrict__ out) {
+    __shared__ uint8_t spec[kHuffSpecBytes];
+    __shared__ CanonicalCode cc[4];
+    __shared__ uint32_t eob_code[2], eob_len[2], ok[4], scan4[4];
+    const uint32_t img = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* hdr = data + scan_offsets[img] - header_bytes;
+    for (uint32_t i = tid; i < kHuffSpecBytes; i += kThreads) spec[i] = hdr[kHuffSpecOffset + i];
+    __syncthreads();
+    if (tid < 4) {
+        const uint32_t at = tid == 0 ? 0u : (tid == 1 ? 29u : (tid == 2 ? 208u : 237u));
+        const bool is_ac = (tid & 1u) != 0;
+        const uint8_t* bits = spec + at + 1;
+        const uint8_t* vals = spec + at + 17;
+        const int n = is_ac ? 162 : 12;
+        bool good = spec[at] == ((is_ac ? 0x10u : 0x00u) | (tid >> 1));
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            cc[tid].mincode[l] = code;
+            cc[tid].valptr[l] = k;
+            k += bits[l - 1];
+            code += bits[l - 1];
+            cc[tid].maxcode[l] = bits[l - 1] ? code - 1 : -1;
+            if (code > (1 << l)) good = false;   // more codes than the length has
+            code <<= 1;
+        }
+        if (k != n) good = false;
+        ok[tid] = good ? 1u : 0u;
+        if (is_ac) {
+            uint32_t ec = 0, el = 0;
+            if (good)
+                for (int l = 1; l <= 16; ++l)
+                    for (int i = 0; i < bits[l - 1]; ++i)
+                        if (vals[cc[tid].valptr[l] + i] == 0x00u) {
+                            ec = (uint32_t)(cc[tid].mincode[l] + i);
+                            el = (uint32_t)l;
+                        }
+            eob_code[tid >> 1] = ec;
+            eob_len[tid >> 1] = el;
+        }
+    }
+    __syncthreads();
+    const bool usable = ok[0] && ok[1] && ok[2] && ok[3];
+    StepTables& t = out[img];
+    for (uint32_t c = 0; c < 2; ++c) {
+        const uint32_t dc_at = c == 0 ? 0u : 208u, ac_at = c == 0 ? 29u : 237u;
+        fill_step_table(t.cls[c].dc, cc[2 * c], spec + dc_at + 1, spec + dc_at + 17, true, eob_code[c], eob_len[c], usable, scan4);
+        fill_step_table(t.cls[c].ac, cc[2 * c + 1], spec + ac_at + 1, spec + ac_at + 17, false, eob_code[c], eob_len[c], usable, scan4);
+    }
+}
+}  // namespace
+
+void launch_build_step_tables(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
+                              uint32_t header_bytes, StepTables* d_tables) {
+    build_step_tables_kernel<<<(unsigned)n_images, kThreads, 0, s>>>(d_data, d_scan_offsets, header_bytes, 0u, d_tables);
+}
+
 DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image) {
     DecodePlan p;
     p.n_images = (uint32_t)n_images;
@@ -1300,6 +1461,7 @@ struct DecodeRun {
     const uint8_t* d_scan = nullptr;
     const uint64_t* d_offsets = nullptr;
     const DecodePrologue* prologue = nullptr;
+    bool tables_per_image = false;   // d_tables is an array, one set per image (launch_build_step_tables)
 
     dim3 grid() const { return dim3(p.n_groups, p.n_images); }
     RawSource source() const { return raw ? RawSource{d_scan, d_offsets, sc.grp_end} : RawSource{}; }
@@ -1320,12 +1482,13 @@ struct DecodeRun {
             decode_sync_kernel<W, true><<<grid(), kThreads, 0, s>>>(nullptr, nullptr, d_sizes, nullptr, p.n_groups, first, d_tables,
                                                                    sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
                                                                    sc.grp_pending, nullptr, nullptr, sc.mode.lum_mask, flag,
-                                                                   source(), rp);
+                                                                   source(), rp, tables_per_image ? 1u : 0u);
         } else {
             decode_sync_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
                                                                     d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
                                                                     sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
-                                                                    sc.first_bad, sc.mode.lum_mask, flag, RawSource{}, RawPrologue{});
+                                                                    sc.first_bad, sc.mode.lum_mask, flag, RawSource{}, RawPrologue{},
+                                                                    tables_per_image ? 1u : 0u);
         }
     }
     template <bool kPlanar, bool kFold, bool kRaw>
@@ -1333,7 +1496,7 @@ struct DecodeRun {
         decode_write_kernel<W, kPlanar, kFold, kRaw><<<grid(), kThreads, 0, s>>>(
             sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, p.total_blocks, d_tables, sc.sub_used, sc.sub_info,
             sc.grp_base, d_coefs, kPlanar ? sc.out_records : nullptr, sc.mode.lum_mask, d_status, sc.grp_sum, sc.sub_end,
-            sc.grp_pending, check, source());
+            sc.grp_pending, check, source(), tables_per_image ? 1u : 0u);
     }
     // The unstuffed-copy decoder is the fall-back for streams that need repair rounds: it always scans in a launch
     // of its own.
@@ -1441,11 +1604,11 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
     if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[0], s);
     switch (p.sub_words) {
         case kSubWordsSmall:
-            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro}.first_pass(follow_up, report);
+            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro, sc.tables_per_image}.first_pass(follow_up, report);
         case kSubWordsMedium:
-            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro}.first_pass(follow_up, report);
+            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro, sc.tables_per_image}.first_pass(follow_up, report);
         default:
-            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro}.first_pass(follow_up, report);
+            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, raw, d_scan, d_offsets, &pro, sc.tables_per_image}.first_pass(follow_up, report);
     }
 }
 
@@ -1454,11 +1617,11 @@ hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const D
                                  const DecodeFollowUp& follow_up, DecodeReport* report) {
     switch (p.sub_words) {
         case kSubWordsSmall:
-            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.repair(follow_up, report);
+            return DecodeRun<kSubWordsSmall>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, false, nullptr, nullptr, nullptr, sc.tables_per_image}.repair(follow_up, report);
         case kSubWordsMedium:
-            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.repair(follow_up, report);
+            return DecodeRun<kSubWordsMedium>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, false, nullptr, nullptr, nullptr, sc.tables_per_image}.repair(follow_up, report);
         default:
-            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status}.repair(follow_up, report);
+            return DecodeRun<kSubWordsLarge>{s, d_sizes, p, sc, d_tables, d_coefs, d_status, false, nullptr, nullptr, nullptr, sc.tables_per_image}.repair(follow_up, report);
     }
 }
 

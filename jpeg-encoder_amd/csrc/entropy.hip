@@ -29,8 +29,10 @@
 // A tile is kTileBlocks = 252 consecutive block-channels (84 MCUs) of one image.
 // Byte ownership: a byte belongs to the tile that holds its first bit, so the
 // byte that straddles two tiles is produced by the earlier tile, which for that
-// purpose also places the first MCU of the next tile (3 block-channels are at
-// least 14 bits, more than the 7 that can be missing).  No atomics on global
+// purpose also places the first kTileOverlap = 4 block-channels of the next tile: with
+// the Annex K codes a block-channel has at least 4 bits, with per-image tables at
+// least 2 (a one-bit DC code and a one-bit end-of-block code), so four of them are
+// at least 8 bits, more than the 7 that can be missing.  No atomics on global
 // memory and no zero-filled output are needed.
 //
 // Slots: the bit string of block j of a tile lives in words slot[w][j],
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const int32_t status_now = *status;                       // looked at after the other loads are under way
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
-    // 252 own block-channels + the first MCU of the next tile (threads 252..254)
-    const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
+    // 252 own block-channels + the first four of the next tile (threads 252..255)
+    const bool has_block = threadIdx.x < kTileBlocks + kTileOverlap && b < nbc;
     // last tile of a stripe that has a successor: one thread stands in for the
     // successor's first blocks with the 32 head bits it was given
     const bool head_thread = st.has_next && tile + 1 == n_tiles && threadIdx.x == kTileBlocks;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
     const uint64_t ubase = img_ubase[img];   // the scans have checked the capacity
     uint8_t* dst = unstuffed + ubase - st.origin_byte;  // indexed by image-stream byte
 
-    // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
+    // this thread's slot: own tile, or column 0..3 of the next tile for the four extra threads
     const uint32_t slot_tile = threadIdx.x < kTileBlocks ? tile : tile + 1;
     const uint32_t slot_col = threadIdx.x < kTileBlocks ? threadIdx.x : threadIdx.x - kTileBlocks;
     const uint32_t* slot = slots + ((size_t)img * n_tiles + slot_tile) * kSlotWords * kSlotStride + slot_col;
@@ -437,9 +439,9 @@ __global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t
     __shared__ uint32_t lens[kEntThreads];
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
-    // 252 own block-channels, and the first MCU of the next tile once more (threads 252..254): the byte that
+    // 252 own block-channels, and the first four of the next tile once more (threads 252..255): the byte that
     // straddles two tiles belongs to the earlier one, whose 0xFF count needs those bits
-    const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
+    const bool has_block = threadIdx.x < kTileBlocks + kTileOverlap && b < nbc;
     BlockRegs blk;
     const int ch = (int)(b % 3u);
     int prev_dc = 0;
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const int32_t status_now = *status;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
-    const bool has_block = threadIdx.x < kTileBlocks + 3 && b < nbc;
+    const bool has_block = threadIdx.x < kTileBlocks + kTileOverlap && b < nbc;
     uint64_t base_bits, ff_before;
     uint32_t own_bits, own_ff, my_len, local_off;
     if (kFold) {
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
     const uint64_t d0 = base_bits >> 5;                      // image-relative dword of window word 0
     const uint32_t rel_start = (uint32_t)(base_bits & 31) + local_off;
     const uint32_t n_words = (uint32_t)((b1 * 8 - d0 * 32 + 31) >> 5);  // words that hold owned bytes
-    // this thread's slot: own tile, or column 0..2 of the next tile for the three extra threads
+    // this thread's slot: own tile, or column 0..3 of the next tile for the four extra threads
     const uint32_t slot_tile = threadIdx.x < kTileBlocks ? tile : tile + 1;
     const uint32_t slot_col = threadIdx.x < kTileBlocks ? threadIdx.x : threadIdx.x - kTileBlocks;
     const uint32_t* slot = slots + ((size_t)img * n_tiles + slot_tile) * kSlotWords * kSlotStride + slot_col;
@@ -920,7 +922,10 @@ __global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __res
     }
     __syncthreads();
     if (lane == 0) {
-        for (int i = 2 * kMax; i > 16; --i) {   // T.81 Figure K.3
+        // T.81 Figure K.3, with 11 bits for DC codes: a block's bit string then never exceeds the 1660 bits that
+        // the Annex K codes can reach, which the slots are sized for
+        const int limit = is_ac ? 16 : 11;
+        for (int i = 2 * kMax; i > limit; --i) {
             while (count[i] > 0) {
                 int j = i - 2;
                 while (count[j] == 0) --j;
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __res
                 count[j] -= 1;
             }
         }
-        int i = 16;
+        int i = limit;
         while (count[i] == 0) --i;
         count[i]--;                             // the extra leaf
     }

@@ -56,7 +56,12 @@ struct DecodeTables {
 //           kStepHasAmp, kStepBad, kStepDcAdd flags
 // fast[] is indexed by the next kFastBits stream bits.  Where longer codes start with those bits the entry
 // has byte 0 = 0 and points to a sub-table of slow[] indexed by the stream bits that follow:
-//   byte 1  mask for those bits (sub-table size - 1),  bytes 2-3  byte offset of the sub-table in the table
+//   byte 1  32 - m for a sub-table of 2^m entries (the right shift that leaves the m bits behind the index bits),
+//   bytes 2-3  byte offset of the sub-table in the table.
+// The tables of the Annex K codes (built on the host) use sub-tables of 2^(16 - kFastBits) entries throughout; the
+// tables built on the device from a file's own DHT segment size each sub-table by the longest code under its
+// prefix, which makes any code with the format's alphabets fit the same slow[] sizes (at most one oversized
+// sub-table per code length: 162 + 2 + 4 + ... + 32 entries).
 // Combined entries: sparse blocks are a DC symbol, a few AC symbols and the end-of-block code, so most look-ups
 // of a smooth picture would be end-of-block codes.  Where a symbol with its amplitude bits AND the
 // end-of-block code of the same table class behind it fit into the kFastBits index bits, the entry stands for
@@ -103,6 +108,7 @@ struct HeaderBytes {
 // Entropy coding works on tiles of kTileBlocks consecutive block-channels of
 // one image (84 MCUs); tiles never straddle images.
 constexpr int kTileBlocks = 252;
+constexpr int kTileOverlap = 4;   // block-channels of the next tile that a tile's workgroup handles once more
 // Bit string of one block-channel: at most 22 + 63 * 26 = 1660 bits = 52 words.
 // A tile's slots are a [kSlotWords][kSlotStride] word array, block j in column j.
 constexpr int kSlotWords = 52;
@@ -224,6 +230,7 @@ struct DecodeScratch {
     uint32_t* changed;       // [4] round flags
     uint32_t* grp_pending;   // [n][n_groups] workgroup ran out of repair steps in the last round
     uint32_t* grp_end;       // [n][n_groups] raw decoder: end state of the group's last sub-sequence
+    bool tables_per_image = false;   // the StepTables pointer given to the launch functions is an array, one per image
     uint32_t* sub_guess;     // [n][subs] start states offered from the stream context
     uint32_t* first_bad;     // [n] first sub-sequence that is not proven yet
     unsigned long long* ctx_keys;   // [ctx_slots] context hash table (power-of-two size): keys ...
@@ -285,6 +292,12 @@ hipError_t launch_entropy_decode(hipStream_t s, const uint8_t* d_scan, const uin
                                  const StepTables* d_tables, int16_t* d_coefs, int32_t* d_status,
                                  const DecodeFollowUp& follow_up, DecodeReport* report,
                                  const DecodePrologue& prologue, bool raw);
+
+// One StepTables per image from the DHT segment of its file (d_scan_offsets[i] - header_bytes is where file i's
+// header starts in d_data): for files written with per-image Huffman tables.  A segment that is not a usable
+// set of tables gives tables in which no code decodes.
+void launch_build_step_tables(hipStream_t s, const uint8_t* d_data, const uint64_t* d_scan_offsets, size_t n_images,
+                              uint32_t header_bytes, StepTables* d_tables);
 
 // The decoder's first step on its own: the unstuffed copy of every stream (sc.ustream at sc.ubase[i]) and the
 // number of dropped bytes per stream (sc.img_drops).  Needs sc.chunk_drops, chunk_base, img_drops, ubase, ustream, changed.

@@ -626,8 +626,9 @@ int jo_encode(const uint8_t* rgb, int w, int h, int quality, uint8_t* out, size_
 /*  2. leaves sorted by (weight, id descending); Huffman tree by the two-queue */
 /*     method: of the heads of the leaf queue and of the queue of merged       */
 /*     nodes (in creation order) the lighter one is taken, a leaf on a tie.    */
-/*  3. code length = depth; lengths above 16 are brought down as in T.81       */
-/*     Figure K.3; the extra leaf's count leaves the longest length in use.    */
+/*  3. code length = depth; lengths above 16 (AC) or 11 (DC, like the Annex K   */
+/*     codes) are brought down as in T.81 Figure K.3; the extra leaf's count   */
+/*     leaves the longest length in use.                                       */
 /*  4. symbols ordered by (depth, id) take the lengths in ascending order:     */
 /*     that order is the table's value list (T.81 Annex C gives the codes).    */
 /* ------------------------------------------------------------------------- */
@@ -675,14 +676,15 @@ static void jo_optimal_table(const uint32_t* freq /*[256]*/, int is_ac, uint8_t 
     memset(count, 0, sizeof(count));
     int leaf_depth[163];          /* by id */
     for (int i = 0; i < N; ++i) { leaf_depth[order[i]] = depth[i]; count[depth[i]]++; }
-    for (int i = 2 * 163; i > 16; --i) {      /* T.81 Figure K.3 */
+    const int limit = is_ac ? 16 : 11;        /* DC codes stay within the 11 bits of the Annex K ones */
+    for (int i = 2 * 163; i > limit; --i) {   /* T.81 Figure K.3 */
         while (count[i] > 0) {
             int j = i - 2;
             while (count[j] == 0) --j;
             count[i] -= 2; count[i - 1] += 1; count[j + 1] += 2; count[j] -= 1;
         }
     }
-    { int i = 16; while (count[i] == 0) --i; count[i]--; }
+    { int i = limit; while (count[i] == 0) --i; count[i]--; }
     for (int l = 1; l <= 16; ++l) bits_out[l - 1] = (uint8_t)count[l];
     uint32_t skey[162];
     for (int i = 0; i < n; ++i) skey[i] = (uint32_t)leaf_depth[i] << 8 | (uint32_t)i;

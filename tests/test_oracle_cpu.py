@@ -161,3 +161,30 @@ def test_edge_replication(po):
     ext[:7, 13:] = rgb[:, 12:13]
     ext[7:] = ext[6:7]
     assert np.array_equal(po.image_to_coefs(rgb, lum, chrom), po.image_to_coefs(ext, lum, chrom))
+
+
+def test_optimised_tables_mode(po):
+    """Per-image Huffman tables: this build's own procedure (the reference has none, entropy_encoder.cpp:614), so
+    nothing of the reference pins it -- parity unpinned.  What can be checked on the CPU: an independent decoder
+    (libjpeg behind PIL) reads such a file and gets the pixels of the file with the Annex K tables; the layout of
+    the 607-byte header is unchanged; DC codes stay within 11 bits, AC codes within 16, no code is all ones; the
+    oracle reads its own file back; files do not grow beyond the three bytes a worse last byte may cost."""
+    import io
+
+    Image = pytest.importorskip("PIL.Image")
+    for (w, h, mode, q) in [(64, 48, 0, 75), (200, 120, 1, 90), (512, 512, 0, 50), (37, 21, 1, 100), (8, 8, 0, 10), (97, 33, 3, 60)]:
+        rgb = po.gen_image(w, h, mode, 5)
+        std, opt = po.encode(rgb, q), po.encode_optimised(rgb, q)
+        assert opt[:177] == std[:177] and opt[593:607] == std[593:607]
+        assert len(opt) <= len(std) + 3
+        spec = opt[177:593]
+        for at, n, limit in ((0, 12, 11), (29, 162, 16), (208, 12, 11), (237, 162, 16)):
+            bits = list(spec[at + 1: at + 17])
+            assert sum(bits) == n and all(b == 0 for b in bits[limit:])
+            assert sum(b * 2 ** (16 - l - 1) for l, b in enumerate(bits)) < 2 ** 16       # room left for the all-ones word
+            assert sorted(spec[at + 17: at + 17 + n]) == sorted(std[177 + at + 17: 177 + at + 17 + n])
+        a = np.asarray(Image.open(io.BytesIO(std)).convert("RGB"))
+        b = np.asarray(Image.open(io.BytesIO(opt)).convert("RGB"))
+        assert np.array_equal(a, b)
+        assert np.array_equal(po.decode_file_tables(opt, w, h, q), po.decode(std, w, h, q))
+        assert po.encode(rgb, q) == std                                                     # the mode leaves nothing behind
