@@ -139,6 +139,14 @@ int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uin
 int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
                     uint16_t chr_q[64]);
 
+/* The same for files that may carry per-image Huffman tables (jea_set_huffman_optimised): those are accepted
+ * when their DHT segment has this library's layout -- the four table ids in the reference's order
+ * (entropy_encoder.cpp:672-693), 12 and 162 values, DC codes of at most 11 bits -- and *own_huffman_tables
+ * says whether the tables differ from the reference's.  If they do, decode with a context on which
+ * jea_set_huffman_optimised(ctx, 1) has been called.  No counterpart in the reference. */
+int jea_read_header_ex(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
+                       uint16_t chr_q[64], int* own_huffman_tables);
+
 /* ---- whole encode: Encoder::encode, encoder.cpp:14-42 ------------------ */
 
 /* Encodes `n_images` equally sized device-resident images in one pass and

@@ -14,7 +14,7 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "HIP", 3: "CAPACITY", 4: "RANGE", 5: "BAD_HEAD
 EXPORTS = [
     "jea_create", "jea_destroy", "jea_last_error", "jea_set_stream", "jea_set_colour_mapper", "jea_get_stream", "jea_synchronize",
     "jea_set_profiling", "jea_last_phase_ms", "jea_set_scratch_budget", "jea_set_huffman_optimised",
-    "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header",
+    "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header", "jea_read_header_ex",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_encode_batch_static_async", "jea_static_scratch_needed",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
@@ -70,6 +70,7 @@ def load_library():
     lib.jea_max_jpeg_bytes.restype = sz
     lib.jea_check_header.argtypes = [vp, sz, c.POINTER(u16), c.POINTER(u16), c.POINTER(c.c_char_p)]
     lib.jea_read_header.argtypes = [vp, sz, c.POINTER(u16), c.POINTER(u16), vp, vp]
+    lib.jea_read_header_ex.argtypes = [vp, sz, c.POINTER(u16), c.POINTER(u16), vp, vp, c.POINTER(i32)]
     lib.jea_encode_batch.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp]
     lib.jea_encode_batch_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
     lib.jea_encode_host.argtypes = [vp, vp, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
@@ -149,6 +150,19 @@ def read_header(jpeg):
     if rc:
         raise JeaError(rc, "jea_read_header: not a file of this format")
     return w.value, h.value, lum, chrom
+
+
+def read_header_ex(jpeg):
+    """(width, height, lum_q, chr_q, own_huffman_tables): read_header for files that may carry per-image Huffman tables."""
+    lib = load_library()
+    buf = np.frombuffer(jpeg, np.uint8)
+    w, h, own = ctypes.c_uint16(0), ctypes.c_uint16(0), ctypes.c_int32(0)
+    lum, chrom = np.zeros(64, np.uint16), np.zeros(64, np.uint16)
+    rc = lib.jea_read_header_ex(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), lum.ctypes.data,
+                                chrom.ctypes.data, ctypes.byref(own))
+    if rc:
+        raise JeaError(rc, "jea_read_header_ex: not a file of this format")
+    return w.value, h.value, lum, chrom, bool(own.value)
 
 
 STATIC_SCRATCH_BYTES = 48 << 20

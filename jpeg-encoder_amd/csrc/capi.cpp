@@ -655,9 +655,9 @@ size_t jea_max_jpeg_bytes(uint16_t width, uint16_t height) {
     return JEA_HEADER_BYTES + 2 * ((mcus_of(width, height) * 3 * 1660 + 7) / 8) + 3;
 }
 
-int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
-                    uint16_t chr_q[64]) {
-    if (!width || !height || !lum_q || !chr_q) return JEA_ERR_INVALID_ARG;
+int jea_read_header_ex(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
+                       uint16_t chr_q[64], int* own_huffman_tables) {
+    if (!width || !height || !lum_q || !chr_q || !own_huffman_tables) return JEA_ERR_INVALID_ARG;
     const int rc = jea_check_header(h_jpeg, len, width, height, nullptr);
     if (rc) return rc;
     // DQT segment at byte 20: marker, length, then {table id, 64 entries in zig-zag order} twice
@@ -668,13 +668,39 @@ int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t
         chr_q[kZigzag[k]] = dqt[5 + 65 + k];
         if (dqt[5 + k] == 0 || dqt[5 + 65 + k] == 0) return JEA_ERR_BAD_HEADER;
     }
-    // DHT segment at byte 173 (420 bytes: marker, length, four tables).  The decoder's tables are the ones
-    // the reference writes (entropy_encoder.cpp:614-694); a file that declares others cannot be decoded by
-    // them, and the reference, which skips the segment (encoder.cpp:240), would decode it wrongly.
+    // DHT segment at byte 173 (420 bytes: marker, length, four tables).  Either the tables the reference writes
+    // (entropy_encoder.cpp:614-694), or per-image ones in the same layout: the same four ids in the same order,
+    // 12 and 162 values, DC codes of at most 11 bits.
     uint8_t own[JEA_HEADER_BYTES];
     jea_write_header(own, *width, *height, lum_q, chr_q);
-    if (memcmp(own + 173, h_jpeg + 173, 2 + 2 + 4 + 412) != 0) return JEA_ERR_BAD_HEADER;
+    if (memcmp(own + 173, h_jpeg + 173, 4) != 0) return JEA_ERR_BAD_HEADER;
+    *own_huffman_tables = memcmp(own + kHuffSpecOffset, h_jpeg + kHuffSpecOffset, kHuffSpecBytes) != 0 ? 1 : 0;
+    if (*own_huffman_tables) {
+        const size_t at[4] = {0, 29, 208, 237};
+        for (int t = 0; t < 4; ++t) {
+            const uint8_t* tab = h_jpeg + kHuffSpecOffset + at[t];
+            if (tab[0] != own[kHuffSpecOffset + at[t]]) return JEA_ERR_BAD_HEADER;
+            unsigned n = 0, code = 0;
+            for (int l = 1; l <= 16; ++l) {
+                n += tab[l];
+                code = (code + tab[l]) << 1;
+                if (code > (2u << l)) return JEA_ERR_BAD_HEADER;          // more codes than the length has
+                if (!(t & 1) && l > 11 && tab[l]) return JEA_ERR_BAD_HEADER;
+            }
+            if (n != ((t & 1) ? 162u : 12u)) return JEA_ERR_BAD_HEADER;
+        }
+    }
     return JEA_OK;
+}
+
+int jea_read_header(const uint8_t* h_jpeg, size_t len, uint16_t* width, uint16_t* height, uint16_t lum_q[64],
+                    uint16_t chr_q[64]) {
+    // The decoder's built-in tables are the ones the reference writes; a file that declares others cannot be
+    // decoded by them, and the reference, which skips the segment (encoder.cpp:240), would decode it wrongly.
+    int own_tables = 0;
+    const int rc = jea_read_header_ex(h_jpeg, len, width, height, lum_q, chr_q, &own_tables);
+    if (rc) return rc;
+    return own_tables ? JEA_ERR_BAD_HEADER : JEA_OK;
 }
 
 int jea_check_header(const uint8_t* h_jpeg, size_t len, uint16_t* hdr_width, uint16_t* hdr_height,

@@ -599,6 +599,27 @@ RunLengthEncodedBlockChannelData HuffmanEncoder::removeFinalEncoding(BitStream c
     return out;
 }
 
+// ---- per-image Huffman tables -----------------------------------------------------------
+
+OptimisedHuffmanEncoder::OptimisedHuffmanEncoder() = default;
+
+namespace {
+[[noreturn]] void perImageTablesNeedTheWholeImage() {
+    throw std::runtime_error("OptimisedHuffmanEncoder codes whole images only (its tables need a pass over all blocks first)");
+}
+}  // namespace
+
+void OptimisedHuffmanEncoder::encodeHeaderEntropyTables(BitStream&) const { perImageTablesNeedTheWholeImage(); }
+
+void OptimisedHuffmanEncoder::applyFinalEncoding(RunLengthEncodedBlockChannelData const&, BitStream&, bool) const {
+    perImageTablesNeedTheWholeImage();
+}
+
+RunLengthEncodedBlockChannelData OptimisedHuffmanEncoder::removeFinalEncoding(BitStream const&, BitStreamReadProgress&,
+                                                                              bool) const {
+    perImageTablesNeedTheWholeImage();
+}
+
 // ---- encoder -----------------------------------------------------------------------------
 
 Encoder::Encoder(std::unique_ptr<ColourMapper> colourMapper,
@@ -623,6 +644,10 @@ jea_ctx* Encoder::context() {
     const bool passThrough = m_colourMapper && m_colourMapper->deviceCapability() == DeviceColourMapping::rgbPassThrough;
     if (jea_set_colour_mapper(m_context, passThrough ? JEA_MAPPER_RGB : JEA_MAPPER_YCBCR) != JEA_OK)
         throw std::runtime_error(std::string("GPU context: ") + jea_last_error(m_context));
+    // ... and its Huffman tables follow the injected entropy coder
+    const bool perImage = m_entropyEncoder && m_entropyEncoder->deviceCapability() == DeviceEntropyCoding::perImageHuffman;
+    if (jea_set_huffman_optimised(m_context, perImage ? 1 : 0) != JEA_OK)
+        throw std::runtime_error(std::string("GPU context: ") + jea_last_error(m_context));
     return m_context;
 }
 
@@ -641,7 +666,8 @@ bool Encoder::allOnDevice() const {
                              (typeid(mapper) == typeid(RGBToRGBMapper) && mapper.deviceCapability() == DeviceColourMapping::rgbPassThrough);
     return knownMapper &&
            typeid(transformer) == typeid(SeparatedDiscreteCosineTransformer) && transformer.deviceCapability() == DeviceTransform::separatedFloat &&
-           typeid(coder) == typeid(HuffmanEncoder) && coder.deviceCapability() == DeviceEntropyCoding::annexKHuffman;
+           ((typeid(coder) == typeid(HuffmanEncoder) && coder.deviceCapability() == DeviceEntropyCoding::annexKHuffman) ||
+            (typeid(coder) == typeid(OptimisedHuffmanEncoder) && coder.deviceCapability() == DeviceEntropyCoding::perImageHuffman));
 }
 
 // Encoder::encode as the reference runs it (encoder.cpp:16-37, header :74-138): every step through the injected

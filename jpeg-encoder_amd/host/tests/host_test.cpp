@@ -269,6 +269,36 @@ int main(int argc, char** argv) {
         broken.encode(bmp, c);
         std::printf("bad_entries_done\n");
     }
+    {   // the injected coder with per-image tables: a smaller file that decodes to the same pixels; mixed with a
+        // user's component it cannot work (two passes do not fit the per-block loop) and says so
+        class WithTables final : public jpeg::Encoder {
+        public:
+            explicit WithTables(std::unique_ptr<jpeg::ColourMapper> m)
+                : Encoder(std::move(m), std::make_unique<jpeg::SeparatedDiscreteCosineTransformer>(),
+                          std::make_unique<jpeg::Quantiser>(60), std::make_unique<jpeg::OptimisedHuffmanEncoder>()) {}
+        private:
+            bool supportsSaving() const override { return true; }
+        };
+        WithTables tailored(std::make_unique<jpeg::RGBToYCbCrMapper>());
+        jpeg::BaselineEncoder baseline(60);
+        jpeg::BitmapImageRGB bmp = make_image(160, 96, 0, 12);
+        jpeg::JPEGImage a, b;
+        tailored.encode(bmp, a);
+        baseline.encode(bmp, b);
+        jpeg::BitmapImageRGB da, db;
+        tailored.decode(a, da);
+        baseline.decode(b, db);
+        const bool sameDec = da.m_imageData.size() == db.m_imageData.size() && !da.m_imageData.empty() &&
+                             std::memcmp(da.m_imageData.data(), db.m_imageData.data(), da.m_imageData.size() * 3) == 0;
+        std::printf("tailored_tables bytes %zu baseline %zu decode_matches %d jpeg_fnv %016llx\n", a.m_compressedImageData.getSize(),
+                    b.m_compressedImageData.getSize(), int(sameDec),
+                    (unsigned long long)fnv(a.m_compressedImageData.getDataPtr(), a.m_compressedImageData.getSize(), basis));
+        class Identity final : public jpeg::RGBToYCbCrMapper {};
+        WithTables mixed(std::make_unique<Identity>());
+        jpeg::JPEGImage c;
+        mixed.encode(bmp, c);
+        std::printf("tailored_tables_mixed bytes %zu\n", c.m_compressedImageData.getSize());
+    }
     {   // wall time of the two calls a user of the classes makes, on a 3840x2160 picture
         jpeg::BitmapImageRGB bmp = make_image(3840, 2160, 0, 1234);
         jpeg::BaselineEncoder encoder(75);

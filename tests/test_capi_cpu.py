@@ -103,3 +103,24 @@ def test_missing_library_fails_loudly(jea, monkeypatch, tmp_path):
         assert "not found" in str(e)
     else:
         raise AssertionError("a missing library must raise")
+
+
+def test_read_header_ex_accepts_per_image_tables(jea, po):
+    """jea_read_header refuses files whose DHT segment is not the reference's; jea_read_header_ex accepts per-image
+    tables in the same layout and says so."""
+    rgb = po.gen_image(80, 56, 1, 2)
+    std, opt = po.encode(rgb, 70), po.encode_optimised(rgb, 70)
+    w, h, lum, chrom, own = jea.binding.read_header_ex(std)
+    assert (w, h, own) == (80, 56, False)
+    w, h, lum2, chrom2, own = jea.binding.read_header_ex(opt)
+    assert (w, h, own) == (80, 56, True) and (lum2 == lum).all() and (chrom2 == chrom).all()
+    with pytest.raises(jea.JeaError):
+        jea.binding.read_header(opt)
+    bad = bytearray(opt)
+    bad[177 + 1 + 11] = 1            # a DC code of 12 bits
+    with pytest.raises(jea.JeaError):
+        jea.binding.read_header_ex(bytes(bad))
+    bad = bytearray(opt)
+    bad[177 + 29] = 0x11             # wrong table id
+    with pytest.raises(jea.JeaError):
+        jea.binding.read_header_ex(bytes(bad))

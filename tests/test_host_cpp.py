@@ -63,6 +63,12 @@ def test_baseline_encoder_cpp_on_gpu(tmp_path):
     # a user's entropy coder that overrides the protected final-encoding step of the reference's interface
     assert "user_entropy_coder encode_matches 1 decode_matches 1 encoded %d decoded %d" % (3 * 4 * 3, 3 * 4 * 3) in lines, r.stdout
     assert "[Error]: Invalid runtime encoding encountered." in lines and "bad_entries_done" in lines
+    # the injected coder with per-image tables against the oracle's statement of the procedure
+    t = next(ln.split() for ln in lines if ln.startswith("tailored_tables bytes"))
+    want = po.encode_optimised(po.gen_image(160, 96, 0, 12), 60)
+    assert int(t[2]) == len(want) and int(t[2]) < int(t[4]) and t[6] == "1" and t[8] == po.fnv(want), r.stdout
+    assert "[Error]: OptimisedHuffmanEncoder codes whole images only (its tables need a pass over all blocks first)" in lines
+    assert "tailored_tables_mixed bytes 173" in lines      # the header up to the table segment, as the reference would leave it
     assert "[Error]: Failed to find SOI marker" in lines
     assert "broken_header_pixels 0" in lines
     assert "bmp_round_trip 1" in lines
