@@ -103,3 +103,25 @@ def test_optimised_random_cases(octx, po, jea):
         got = octx.encode_host(rgb, lum, chrom)
         assert got == want, (case, w, h, q, mode)
         assert np.array_equal(octx.decode_host(got, w, h, lum, chrom), po.decode_file_tables(want, w, h, q)), (case, w, h, q, mode)
+
+
+def test_entry_points_without_the_mode_refuse_it(octx, po, jea):
+    """Stripes (the symbol counts would need an exchange) and the static-scratch encode keep the Annex K tables: in
+    the mode they return an error instead of writing a file the caller did not ask for."""
+    import torch
+
+    w, h = 64, 32
+    lum, chrom = jea.binding.quant_tables(75)
+    d_rgb = octx.to_device(po.gen_image(w, h, 0, 1).reshape(-1))
+    with pytest.raises(jea.JeaError):
+        octx.stripe_transform(d_rgb, w, h, lum, chrom)
+    out = torch.empty(1 << 16, dtype=torch.uint8, device=octx.tdev)
+    off = torch.zeros(1, dtype=torch.int64, device=octx.tdev)
+    size = torch.zeros(1, dtype=torch.int64, device=octx.tdev)
+    status = torch.zeros(16, dtype=torch.int32, device=octx.tdev)
+    with pytest.raises(jea.JeaError):
+        octx.encode_batch_static_async(d_rgb, 1, w, h, lum, chrom, out, off, size, status)
+    octx.set_huffman_optimised(False)
+    octx.encode_batch_static_async(d_rgb, 1, w, h, lum, chrom, out, off, size, status)
+    octx.synchronize()
+    assert out[: int(size[0])].cpu().numpy().tobytes() == po.encode(po.gen_image(w, h, 0, 1), 75)
