@@ -813,11 +813,21 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
 
 template <bool kPlanar>
 __global__ __launch_bounds__(kEntThreads) void symbol_histogram_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
+                                                                       uint32_t n_tiles,
                                                                        const uint8_t* __restrict__ chunk_masks,
                                                                        ComponentMode mode, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[2 * 512];   // [class][DC symbols at 0, AC symbols at 256]
-    const uint32_t tile = blockIdx.x, img = blockIdx.y;
-    for (uint32_t i = threadIdx.x; i < 1024; i += kEntThreads) h[i] = 0;
+    // [copy][class][DC symbols at 0, AC symbols at 256]: most blocks of a smooth picture count the same two or three
+    // symbols, and atomics of one wave on one address go one after the other; eight copies, chosen by lane,
+    // cut those queues to an eighth
+    constexpr uint32_t kCopies = 8;
+    __shared__ uint32_t hc[kCopies][2 * 512];
+    uint32_t* const h = hc[threadIdx.x & (kCopies - 1)];
+    const uint32_t img = blockIdx.y;
+    for (uint32_t i = threadIdx.x; i < kCopies * 1024; i += kEntThreads) (&hc[0][0])[i] = 0;
+    __syncthreads();
+    // A workgroup takes every gridDim.x-th tile: what it adds to the image's counts in the end are atomics of all
+    // workgroups on the same few addresses, and with one workgroup per tile those took 30 us for a 4K picture.
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
     const bool has_block = threadIdx.x < kTileBlocks && b < nbc;
     BlockRegs blk;
@@ -835,16 +845,20 @@ __global__ __launch_bounds__(kEntThreads) void symbol_histogram_kernel(const int
             prev_dc = (b >= 3) ? (int)p[-192] : 0;
         }
     }
-    __syncthreads();
     if (has_block) {
         HistSink sink;
         sink.hist = h + (mode.is_lum((uint32_t)ch) ? 0 : 512);
         // the code tables only shape the bits, which this sink throws away: any readable words will do
         (void)encode_block(blk, prev_dc, h, h, sink);
     }
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 1024; i += kEntThreads)
-        if (h[i] != 0) atomicAdd(&hist[(size_t)img * 1024 + i], h[i]);
+    for (uint32_t i = threadIdx.x; i < 1024; i += kEntThreads) {
+        uint32_t n = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < kCopies; ++c) n += hc[c][i];
+        if (n != 0) atomicAdd(&hist[(size_t)img * 1024 + i], n);
+    }
 }
 
 // id of an AC symbol in the ascending list of the 162 symbols the format has (sizes 1..10 with runs 0..15, the
@@ -857,8 +871,9 @@ __device__ __forceinline__ int ac_symbol_id(uint32_t s) {
     return (int)(1u + run * 10u + (ss - 1u) + (run == 15u ? 1u : 0u));
 }
 
-// One wave per table: blockIdx.x = table in header order (lum DC, lum AC, chr DC, chr AC), blockIdx.y = image.
-__global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __restrict__ hist, HuffTables* __restrict__ tables,
+// One workgroup per table: blockIdx.x = table in header order (lum DC, lum AC, chr DC, chr AC), blockIdx.y = image.
+// The sorts and the code assignment use all threads; the tree is one thread's work.
+__global__ __launch_bounds__(kEntThreads) void build_huffman_kernel(const uint32_t* __restrict__ hist, HuffTables* __restrict__ tables,
                                                            uint8_t* __restrict__ spec) {
     constexpr int kMax = 163;
     __shared__ unsigned long long key[kMax + 1];
@@ -869,24 +884,29 @@ __global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __res
     __shared__ uint32_t count[2 * kMax + 2];
     __shared__ uint16_t leaf_depth[kMax + 1];
     __shared__ uint8_t vals[kMax];
+    constexpr uint32_t kT = kEntThreads;
+    __shared__ int max_depth;
     const uint32_t t = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
     const bool is_ac = (t & 1u) != 0;
     const uint32_t cls = t >> 1;
     const int n = is_ac ? 162 : 12, N = n + 1;
     const uint32_t* freq = hist + ((size_t)img * 4 + t) * 256;
     // 1. leaves: weight = occurrences + 1, and the extra leaf of weight 0; key ascending = (weight, id descending)
-    for (uint32_t s = lane; s < 256; s += 64) {
+    for (uint32_t s = lane; s < 256; s += kT) {
         const int id = is_ac ? ac_symbol_id(s) : (s < 12u ? (int)s : -1);
         if (id >= 0) {
             syms[id] = (uint8_t)s;
             key[id] = ((unsigned long long)freq[s] + 1ull) << 9 | (unsigned long long)(511 - id);
         }
     }
-    if (lane == 0) key[n] = (unsigned long long)(511 - n);
-    for (uint32_t i = lane; i < 2 * kMax + 2; i += 64) count[i] = 0;
+    if (lane == 0) {
+        key[n] = (unsigned long long)(511 - n);
+        max_depth = 0;
+    }
+    for (uint32_t i = lane; i < 2 * kMax + 2; i += kT) count[i] = 0;
     __syncthreads();
     // 2. sort by counting smaller keys (the keys are distinct)
-    for (int i = (int)lane; i < N; i += 64) {
+    for (int i = (int)lane; i < N; i += (int)kT) {
         const unsigned long long k = key[i];
         int rank = 0;
         for (int j = 0; j < N; ++j) rank += key[j] < k ? 1 : 0;
@@ -897,21 +917,38 @@ __global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __res
     // two queues: leaves in sorted order (nodes 0..N-1), merged nodes in creation order (N..2N-2); the lighter head
     // is taken, the leaf on a tie
     if (lane == 0) {
+        // the heads of both queues and the entries behind them stay in registers: the loop is one lane's chain of
+        // dependent steps, and a read of LDS in it costs as much as twenty instructions
+        constexpr unsigned long long kNone = ~0ull;
         int lh = 0, ih = N, made = N;
+        unsigned long long l0 = weight[0], l1 = N > 1 ? weight[1] : kNone, i0 = kNone, i1 = kNone;
         for (int m = 0; m < N - 1; ++m) {
             int pick[2];
+            unsigned long long sum = 0;
             for (int k = 0; k < 2; ++k) {
-                if (lh < N && (ih >= made || weight[lh] <= weight[ih])) pick[k] = lh++;
-                else pick[k] = ih++;
+                if (l0 != kNone && (i0 == kNone || l0 <= i0)) {
+                    pick[k] = lh++;
+                    sum += l0;
+                    l0 = l1;
+                    l1 = lh + 1 < N ? weight[lh + 1] : kNone;
+                } else {
+                    pick[k] = ih++;
+                    sum += i0;
+                    i0 = i1;
+                    i1 = ih + 1 < made ? weight[ih + 1] : kNone;
+                }
             }
-            weight[made] = weight[pick[0]] + weight[pick[1]];
+            weight[made] = sum;
             parent[pick[0]] = parent[pick[1]] = (uint16_t)made;
+            // the new node joins the queue of merged nodes: it is its head, the one behind the head, or further back
+            if (i0 == kNone) i0 = sum;
+            else if (i1 == kNone && ih + 1 == made) i1 = sum;
             ++made;
         }
     }
     __syncthreads();
     // 3. depth of every leaf = steps up to the root, node 2N-2
-    for (int i = (int)lane; i < N; i += 64) {
+    for (int i = (int)lane; i < N; i += (int)kT) {
         int v = i, d = 0;
         while (v != 2 * N - 2) {
             v = parent[v];
@@ -919,13 +956,14 @@ __global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __res
         }
         leaf_depth[order[i]] = (uint16_t)d;
         atomicAdd(&count[d], 1u);
+        atomicMax(&max_depth, d);
     }
     __syncthreads();
     if (lane == 0) {
         // T.81 Figure K.3, with 11 bits for DC codes: a block's bit string then never exceeds the 1660 bits that
         // the Annex K codes can reach, which the slots are sized for
         const int limit = is_ac ? 16 : 11;
-        for (int i = 2 * kMax; i > limit; --i) {
+        for (int i = max_depth; i > limit; --i) {
             while (count[i] > 0) {
                 int j = i - 2;
                 while (count[j] == 0) --j;
@@ -940,7 +978,7 @@ __global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __res
         count[i]--;                             // the extra leaf
     }
     // 4. symbols by (depth, id): the value list
-    for (int i = (int)lane; i < n; i += 64) {
+    for (int i = (int)lane; i < n; i += (int)kT) {
         const uint32_t k = (uint32_t)leaf_depth[i] << 8 | (uint32_t)i;
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += ((uint32_t)leaf_depth[j] << 8 | (uint32_t)j) < k ? 1 : 0;
@@ -952,17 +990,22 @@ __global__ __launch_bounds__(64) void build_huffman_kernel(const uint32_t* __res
     uint8_t* out = spec + (size_t)img * kHuffSpecBytes + at;
     uint32_t* codes = is_ac ? tables[img].ac[cls] : tables[img].dc[cls];
     if (is_ac)
-        for (uint32_t s = lane; s < 256; s += 64) codes[s] = 0;
+        for (uint32_t s = lane; s < 256; s += kT) codes[s] = 0;
     __syncthreads();
     if (lane == 0) out[0] = (uint8_t)((is_ac ? 0x10u : 0x00u) | cls);
     if (lane < 16) out[1 + lane] = (uint8_t)count[1 + lane];
-    for (int i = (int)lane; i < n; i += 64) out[17 + i] = vals[i];
-    if (lane == 0) {
-        uint32_t code = 0;
-        int k = 0;
+    for (int i = (int)lane; i < n; i += (int)kT) out[17 + i] = vals[i];
+    // T.81 Annex C: the k-th value gets the k-th code; every lane works out where its values fall
+    for (int k = (int)lane; k < n; k += (int)kT) {
+        uint32_t code = 0, first = 0;
         for (uint32_t l = 1; l <= 16; ++l) {
-            for (uint32_t i = 0; i < count[l]; ++i, ++k) codes[vals[k]] = code++ | (l << 16);
-            code <<= 1;
+            const uint32_t c = count[l];
+            if ((uint32_t)k < first + c) {
+                codes[vals[k]] = (code + ((uint32_t)k - first)) | (l << 16);
+                break;
+            }
+            code = (code + c) << 1;
+            first += c;
         }
     }
 }
@@ -1002,11 +1045,14 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     if (optimal) {
         // two passes over the coefficients, as the reference's note says: count the symbols, make the tables
         (void)hipMemsetAsync(sc.optimal.hist, 0, n_images * 1024 * sizeof(uint32_t), s);
+        uint32_t per_image = (256u + n - 1) / n;      // about one workgroup per compute unit over the whole job
+        if (per_image > n_tiles) per_image = n_tiles;
+        const dim3 hgrid(per_image, n);
         if (sc.planar)
-            symbol_histogram_kernel<true><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, sc.chunk_masks, sc.mode, sc.optimal.hist);
+            symbol_histogram_kernel<true><<<hgrid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, sc.chunk_masks, sc.mode, sc.optimal.hist);
         else
-            symbol_histogram_kernel<false><<<grid, kEntThreads, 0, s>>>(d_coefs, nbc, sc.chunk_masks, sc.mode, sc.optimal.hist);
-        build_huffman_kernel<<<dim3(4, n), 64, 0, s>>>(sc.optimal.hist, sc.optimal.tables, sc.optimal.spec);
+            symbol_histogram_kernel<false><<<hgrid, kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, sc.chunk_masks, sc.mode, sc.optimal.hist);
+        build_huffman_kernel<<<dim3(4, n), kEntThreads, 0, s>>>(sc.optimal.hist, sc.optimal.tables, sc.optimal.spec);
         d_huff = sc.optimal.tables;
     }
     // The bit-length kernel also tallies the 0xFF bytes; one kernel packs and stuffs.
