@@ -188,7 +188,7 @@ def cpu_encode_baseline(po, images, quality, n_single, threads):
     for i in range(n_single):
         po.encode(images[i % len(images)], quality)
     single = n_single * w * h / (time.perf_counter() - t0) / 1e6
-    n_all = 2 * threads
+    n_all = 8 * threads
     t0 = time.perf_counter()
     with concurrent.futures.ThreadPoolExecutor(threads) as pool:
         list(pool.map(lambda i: po.encode(images[i % len(images)], quality), range(n_all)))
@@ -494,7 +494,7 @@ def config_c3(job):
                                      "scans_pack_stuff": round(ph[2] * 1e3, 1)}
     cpu = None
     if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_encode_baseline(po, frames[:32], QUALITY, 32, CPU_THREADS)
+        cpu = cpu_encode_baseline(po, frames[:64], QUALITY, 192, CPU_THREADS)
     out = {"metric": "encode MPix/s (q=90)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -685,7 +685,7 @@ def main():
                     help="untimed steps before the warm-up, for the GPU clocks (0 for counter-collection runs)")
     ap.add_argument("--quick", action="store_true", help="c2: only the headline measurement and the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=10, help="c2: images of the single-thread CPU sample")
+    ap.add_argument("--cpu-images", type=int, default=48, help="c2: images of the single-thread CPU sample")
     args = ap.parse_args()
     defaults = {"c2": (2000, 200), "c3": (10, 2), "c4": (10, 2), "c5": (10, 2)}[args.config]
     if args.steps is None:
