@@ -9,6 +9,8 @@ import pyoracle as po
 import torch
 
 w, h, q, mode, n = (int(a) for a in sys.argv[1:6])
+if os.environ.get("JEA_LIB"):   # a build made by tools/build_variant.sh
+    jea.binding.LIB_PATH = os.path.join(ROOT, "jpeg-encoder_amd", os.environ["JEA_LIB"])
 ctx = jea.Context(0)
 lum, chrom = jea.binding.quant_tables(q)
 if mode == 2:
@@ -18,7 +20,7 @@ else:
     rgb = po.gen_image(w, h, mode, 1234)
 d_rgb = ctx.to_device(np.tile(rgb.reshape(-1), n))
 cap = n * int(jea.binding.max_jpeg_bytes(w, h)) if w * h < 1 << 22 else n * (64 << 20)
-for it in range(4):
+for it in range(6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out, off, size = ctx.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=cap)
     torch.cuda.synchronize(); t1 = time.perf_counter()
