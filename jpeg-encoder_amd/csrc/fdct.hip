@@ -316,6 +316,10 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     // first half is reused for the samples, [channel][mcu][64] u8
     __shared__ __align__(16) uint8_t lds_coef[kFdctThreads * 128];
     uint8_t* const lds_px = lds_coef;
+    // per channel, the MCUs whose block is a DC value alone (all 64 samples equal); and the MCUs that have a
+    // block with more than that, listed
+    __shared__ uint64_t dc_alone_of[3];
+    __shared__ uint8_t varied[kMcusPerGroup];
 
     const int tid = threadIdx.x;
     const uint32_t g0 = blockIdx.x * kMcusPerGroup;
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     float tmp[8][8];
     float dc_only = 0.0f;
     int diag = 7;
+    bool dc_alone = false;
     if (valid) {
         const uint8_t* chunk[8];
 #pragma unroll
@@ -357,6 +362,7 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             const uint4* plane = reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu + mcu;
             rest_nonzero = (mask >> 1) != 0;
             far_nonzero = (mask >> 2) != 0;
+            dc_alone = mask == 0;
             uint4 first = make_uint4(rec & 0xffffu, 0, 0, 0);   // DC alone
             if (mask & 1u) first = plane[0];
             *reinterpret_cast<uint4*>(const_cast<uint8_t*>(chunk[0])) = first;
@@ -381,6 +387,8 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             }
             rest_nonzero = rest != 0;
             far_nonzero = far != 0;
+            const uint4 c0 = *reinterpret_cast<const uint4*>(chunk[0]);
+            dc_alone = (rest | (c0.x >> 16) | c0.y | c0.z | c0.w) == 0;
         }
         if (__ballot(rest_nonzero) == 0) {
             // words of the first chunk: zig-zag positions 0-1 | 2-3 | 4-5 | 6-7, which lie on the
@@ -405,7 +413,18 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             default: idct_rows<7>(chunk, qt, tmp); break;
         }
     }
+    {
+        const uint64_t alone = __ballot(dc_alone);
+        if (m == 0) dc_alone_of[channel] = alone;
+    }
     __syncthreads();   // every coefficient has been read: the samples may overwrite them
+    // An MCU whose three blocks are DC values alone is one colour: it is converted once.  The others go on a list.
+    const uint64_t flat = dc_alone_of[0] & dc_alone_of[1] & dc_alone_of[2];
+    const uint32_t n_varied = mcus_here - (uint32_t)__popcll(flat);
+    if (channel == 0 && valid && !((flat >> m) & 1u)) {
+        const uint64_t others = ~flat;
+        varied[__builtin_amdgcn_mbcnt_hi((uint32_t)(others >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)others, 0u))] = (uint8_t)m;
+    }
     if (valid) {
         uint8_t* dst = lds_px + (channel * kMcusPerGroup + m) * 64;
         switch (diag) {
@@ -429,8 +448,39 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     // segment is whole and 8-byte aligned): work item = (row r, mcu mm) = 8 pixels = 24 contiguous
     // bytes; consecutive threads take consecutive MCUs, i.e. consecutive 24-byte pieces of an image row.
     if ((width & 7) == 0) {
-        for (uint32_t i = tid; i < 8u * mcus_here; i += kFdctThreads) {
-            const uint32_t r = i / mcus_here, mm = i - r * mcus_here;
+        // One colour: thread t takes MCU t / 3 and the 8-byte piece t % 3 of its 24-byte rows, so that the lanes of
+        // a wave write consecutive bytes.
+        const uint32_t fm = (uint32_t)tid / 3u, piece = (uint32_t)tid - 3u * fm;
+        if ((flat >> fm) & 1u) {
+            const uint32_t mcu = g0 + fm;
+            const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+            const int c0 = lds_px[(0 * kMcusPerGroup + fm) * 64], c1 = lds_px[(1 * kMcusPerGroup + fm) * 64],
+                      c2 = lds_px[(2 * kMcusPerGroup + fm) * 64];
+            float px3[3];
+            if (mode.passthrough) {
+                px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
+            } else {
+                bool tie;
+                colour_inverse_fast_unclamped((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);
+                if (tie) {   // the literal formula
+                    uint8_t rr, gg, bb;
+                    colour_inverse(c0, c1, c2, rr, gg, bb);
+                    px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
+                }
+            }
+            // eight pixels are the 24 bytes RGBR GBRG BRGB RGBR GBRG BRGB; piece p starts at byte 8 p, with colour 2 p mod 3
+            uint32_t w2[2] = {0, 0};
+#pragma unroll
+            for (int byte = 0; byte < 8; ++byte) {
+                const uint32_t c = (2u * piece + (uint32_t)byte) % 3u;
+                w2[byte >> 2] = insert_byte(c == 0 ? px3[0] : (c == 1 ? px3[1] : px3[2]), byte & 3, w2[byte >> 2]);
+            }
+            uint8_t* to = img + ((size_t)by * 8 * width + (size_t)bx * 8) * 3 + 8 * piece;
+            const int rows = height - (int)by * 8 < 8 ? height - (int)by * 8 : 8;
+            for (int r = 0; r < rows; ++r) *reinterpret_cast<uint2*>(to + (size_t)r * width * 3) = make_uint2(w2[0], w2[1]);
+        }
+        for (uint32_t i = tid; i < 8u * n_varied; i += kFdctThreads) {
+            const uint32_t r = i / n_varied, mm = varied[i - r * n_varied];
             const uint32_t mcu = g0 + mm;
             const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
             const int y = (int)by * 8 + (int)r;

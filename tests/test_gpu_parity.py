@@ -418,6 +418,36 @@ def test_decode_flat_regions_next_to_detail(ctx, po, jea):
         assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(jpeg, w, h, quality)), quality
 
 
+def test_decode_single_colour_mcus(po, jea):
+    """MCUs whose three blocks are DC values alone are converted once and stored as rows of one colour: lone MCUs
+    with detail among them, a last block row that is cropped (height not a multiple of 8), every colour on a
+    coarse grid (the literal formula behind the rounding ties too), both mappers, and the standard coefficient
+    layout (jea_idct_dequant) beside the decoder's own."""
+    ctx = jea.Context(0)
+    try:
+        for mapper in (0, 1):
+            ctx.set_colour_mapper(mapper)
+            po.set_mapper(mapper)
+            for (w, h) in [(520, 203), (64, 20), (1544, 61)]:
+                rng = np.random.RandomState(w + h + mapper)
+                bw, bh = w // 8, (h + 7) // 8
+                colours = rng.randint(0, 256, (bh, bw, 3)).astype(np.uint8)
+                colours[0, :, :] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255]] * (bw // 5) + [[7, 7, 7]] * (bw % 5)
+                rgb = np.repeat(np.repeat(colours, 8, axis=0), 8, axis=1)[:h, :w].copy()
+                for (y, x) in rng.randint(0, [h, w], (12, 2)):        # detail in a few MCUs
+                    rgb[y, x] = 255 - rgb[y, x]
+                for quality in (50, 100):
+                    lum, chrom = jea.binding.quant_tables(quality)
+                    jpeg = po.encode(rgb, quality)
+                    assert np.array_equal(ctx.decode_host(jpeg, w, h, lum, chrom), po.decode(jpeg, w, h, quality)), (mapper, w, h, quality)
+                    coefs = po.image_to_coefs(rgb, lum, chrom)
+                    got = ctx.idct_dequant(ctx.to_device(coefs.reshape(-1)), 1, w, h, lum, chrom).cpu().numpy().reshape(h, w, 3)
+                    assert np.array_equal(got, po.coefs_to_image(coefs, w, h, lum, chrom)), (mapper, w, h, quality, "standard layout")
+    finally:
+        po.set_mapper(0)
+        ctx.close()
+
+
 def test_decode_damaged_streams_agree_with_oracle(ctx, po, jea):
     """A damaged scan either fails in both decoders or decodes to the same picture in both
     (entropy_encoder.cpp:775-777,825-827 and the bounds of :122-144; encoder.cpp:63-65)."""
