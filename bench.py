@@ -237,7 +237,7 @@ def forward_kernel_roofline(job, ctx, groups, whole, w, h, lum, chrom, images_pe
 
     one = launches(n, 60)
     k_bytes = K1_BYTES_PER_PIXEL * n * w * h
-    roof = {"kernel": "fdct_quant_kernel", "achieved": round(k_bytes / (one * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+    roof = {"kernel": "fdct_quant_rows_kernel", "achieved": round(k_bytes / (one * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(k_bytes / (one * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_us": round(one * 1e3, 2), "algorithmic_bytes_per_launch": int(k_bytes)}
     # The same kernel with several times the work per launch (images of the pool side by side): the difference is

@@ -14,7 +14,12 @@
 //   edges       jpeg/src/block_grid.cpp:8-28 (replicate), :87-99 (crop)
 // This file must be compiled with -ffp-contract=off.
 //
-// Mapping to the machine: a workgroup of 192 threads owns 64 consecutive MCUs.
+// Two forward kernels share the arithmetic (dct_device.h).
+// fdct_quant_rows_kernel -- the fused encode's kernel for pictures whose sides are multiples of 8 (chunk-planar
+// output): lane = one pixel row / one column of a block, the block's values change hands inside the wave through
+// LDS; see the comment above it.
+// fdct_quant_kernel -- every other case (ragged sides, the [mcu][channel][64] layout of the stage-level entry
+// points and of stripes): a workgroup of 192 threads owns 64 consecutive MCUs.
 // Wave w (64 lanes) is channel w (Y, Cb, Cr) and lane l is MCU l, so channel
 // dependent constants are wave-uniform (scalar registers) and one thread carries
 // one whole 8x8 block-channel in registers through both DCT passes -- no
@@ -228,6 +233,213 @@ __global__ __launch_bounds__(kFdctThreads, JEA_K1_MIN_WAVES) void fdct_quant_ker
     for (uint32_t i = tid; i < n_chunks; i += kFdctThreads) {
         const uint32_t jj = i >> 3, kk = i & 7u;
         out[i] = *reinterpret_cast<const uint4*>(lds_out + jj * 128 + (((kk + jj) & 7u) << 4));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The forward kernel of the fused encode for pictures whose width is a multiple of 8: the same arithmetic, laid
+// out over the lanes by block ROW instead of by block.
+//
+// A wave works on 8 consecutive MCUs at a time (a "unit").  Lane l = 8 m + s: m is the MCU; s is, in turn, the
+// pixel row the lane converts and transforms (row pass), the horizontal frequency whose column it transforms
+// and quantises (column pass), and the 16-byte chunk of the finished block that it stores.  Between the phases
+// the 8 x 8 values of a block change hands inside the wave through LDS (no workgroup barrier: a wave's LDS
+// instructions complete in order).  A lane carries one row or column -- 8 values, not 64 -- so
+//   * the three channels of a pixel row are done by one lane one after the other and every byte is converted
+//     to float once, not once per channel,
+//   * the quantised values leave as 16-bit LDS stores at their zig-zag place: no packing instructions,
+//   * the kernel needs few registers, and a wave's work per unit is a few hundred instructions instead of three
+//     thousand: launches have no long tail, and the loads of the next unit are in flight during the arithmetic.
+// A wave takes `units_per_wave` consecutive units; the launcher picks that number so that the waves of a launch
+// fill the compute units evenly.
+constexpr int kRowWaves = 4;
+constexpr int kRowThreads = 64 * kRowWaves;
+// LDS layouts, chosen with the banking rules of the LDS in mind (stores: bank = dword mod 32, conflicts among the 32
+// lanes of a half wave, two-way conflicts hidden behind the store's register transfer; 16-byte loads: bank = dword
+// mod 64, conflicts among four fixed groups of 16 lanes that each take m = 0..3 or 4..7 with s = 0..3 or 4..7):
+//  * transposition buffer, in 16-byte slots: value (frequency u, row y) of MCU m lives in slot
+//    kRowTSlot[m & 3] + 128 (m >> 2) + 66 (y >> 2) + 2 u, word y & 3.  The row pass stores with word offsets 8 u
+//    (two-way conflicts), the column pass loads two slots 66 apart (conflict-free).
+//  * zig-zag buffer: block m starts at word kRowZWord[m & 3] + 148 (m >> 2).
+//  * quantisation tables: row u of a table is 16 floats {RN(1/Q), Q} x 8 at a stride of 20 floats, so that the
+//    eight rows a group of lanes reads lie in different banks.
+constexpr int kRowTSlot[4] = {0, 1, 41, 40};
+constexpr int kRowTWords = 1024;
+constexpr int kRowZWord[4] = {0, 36, 116, 80};
+constexpr int kRowZWords = 320;
+constexpr int kRowQStride = 20;
+
+// The eight sums of discrete_cosine_transform.cpp:103-112 (and :114-124, which has the same shape) over one row
+// or column; products and sums round one by one, in index order (see fdct_row).
+__device__ __forceinline__ void fdct_1d(const float (&in)[8], float (&out)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float acc = fwd_c(u, 0) * in[0];
+#pragma unroll
+        for (int x = 1; x < 8; ++x) acc += fwd_c(u, x) * in[x];
+        out[u] = (u == 0) ? scale_s(0) * acc : acc;
+    }
+}
+
+// what one wave's LDS traffic must not be reordered across (the lanes exchange data with each other)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kRowThreads, 4) void fdct_quant_rows_kernel(
+    const uint8_t* __restrict__ rgb, int width, int height, int blocks_w, uint32_t n_mcu, size_t image_bytes, QuantTables q,
+    int16_t* __restrict__ coefs, int32_t* __restrict__ status_to_clear, uint8_t* __restrict__ chunk_masks, ComponentMode mode,
+    uint32_t units_per_wave) {
+    if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status_to_clear = 0;
+    __shared__ __align__(16) float lds_q[2 * 8 * kRowQStride];   // [table][u]{RN(1/Q), Q}[v]
+    __shared__ uint8_t lds_zpos[64];   // zig-zag position of natural index n
+    __shared__ __align__(16) float lds_t[kRowWaves][kRowTWords];
+    __shared__ __align__(16) uint32_t lds_z[kRowWaves][kRowZWords];
+
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        // lum_t | chr_t and rlum_t | rchr_t lie side by side in QuantTables, entry 8 u + v each
+        const float* qb = reinterpret_cast<const float*>(&q);
+        float* to = lds_q + (tid >> 6) * 8 * kRowQStride + ((tid >> 3) & 7) * kRowQStride + 2 * (tid & 7);
+        to[0] = qb[256 + tid];
+        to[1] = qb[128 + tid];
+    } else if (tid < 192) {
+        lds_zpos[kZigzag[tid - 128]] = (uint8_t)(tid - 128);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lane = (uint32_t)tid & 63u, m = lane >> 3, s = lane & 7u;
+    const uint32_t n_units = (n_mcu + 7u) >> 3;
+    uint32_t unit = ((uint32_t)blockIdx.x * kRowWaves + (uint32_t)wave) * units_per_wave;
+    const uint32_t unit_end = unit + units_per_wave < n_units ? unit + units_per_wave : n_units;
+    if (unit >= unit_end) return;   // no workgroup barrier below
+
+    const uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
+    const uint32_t t_slot = (uint32_t)kRowTSlot[m & 3u] + 128u * (m >> 2);
+    float* const t_write = lds_t[wave] + 4u * (t_slot + 66u * (s >> 2)) + (s & 3u);   // + 8 u: value of frequency u, row s
+    const float* const t_read = lds_t[wave] + 4u * (t_slot + 2u * s);   // rows 0-3 of frequency s; rows 4-7 66 slots on
+    uint8_t* const z_block = reinterpret_cast<uint8_t*>(lds_z[wave] + (uint32_t)kRowZWord[m & 3u] + 148u * (m >> 2));
+    uint32_t z_off[8];   // where coefficient (v, u = s) goes: its zig-zag position, two bytes each
+#pragma unroll
+    for (int v = 0; v < 8; ++v) z_off[v] = 2u * lds_zpos[8 * v + s];
+
+    // colour constants of the three channels in vector registers (an operand in a scalar register halves the
+    // issue rate of an FMA)
+    ColourInt ci[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        ci[ch] = colour_int_constants(ch);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci[ch].k) : "s"(ci[ch].k));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci[ch].a) : "s"(ci[ch].a));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci[ch].b) : "s"(ci[ch].b));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ci[ch].c) : "s"(ci[ch].c));
+    }
+
+    // MCU of this lane in the first unit; later units are 8 MCUs further each.  Width and height are multiples
+    // of 8 here (the launcher's condition), so a row of MCUs is a row of 24 blocks_w bytes, no row is repeated,
+    // and a lane's pixels move 192 bytes per unit, plus seven pixel rows when its MCU wraps into the next row.
+    uint32_t mcu = unit * 8u + m;
+    const uint32_t row_bytes = (uint32_t)width * 3u;
+    const uint32_t mcu_in = mcu < n_mcu ? mcu : n_mcu - 1u;   // the tail of the last unit reads the last MCU, and is never stored
+    // mcu_in / blocks_w through a float quotient and one correction either way (exact: both are below 2^24, the
+    // launcher's condition; the integer division costs twice the instructions)
+    uint32_t by0 = (uint32_t)((float)mcu_in * __builtin_amdgcn_rcpf((float)blocks_w));
+    int32_t bx_signed = (int32_t)mcu_in - (int32_t)(by0 * (uint32_t)blocks_w);
+    if (bx_signed < 0) {
+        bx_signed += blocks_w;
+        by0 -= 1u;
+    } else if (bx_signed >= blocks_w) {
+        bx_signed -= blocks_w;
+        by0 += 1u;
+    }
+    uint32_t bx = (uint32_t)bx_signed;
+    const uint8_t* src = img + ((size_t)by0 * 8 + s) * row_bytes + (size_t)bx * 24;
+    uint2 cur[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cur[i] = reinterpret_cast<const uint2*>(src)[i];
+    // Output addresses as a uniform base plus a 32-bit offset per lane (the launcher checks that a picture's
+    // planes stay below 4 GiB): chunk s of channel ch of this lane's MCU, and the MCU's three mask bytes.
+    const uint32_t plane_bytes = n_mcu * 16u;
+    uint8_t* const out_image = reinterpret_cast<uint8_t*>(coefs) + (size_t)blockIdx.y * 24 * plane_bytes;
+    uint8_t* const mask_image = chunk_masks + (size_t)blockIdx.y * n_mcu * 3;
+    uint32_t out_off = s * 3u * plane_bytes + mcu * 16u, mask_off = mcu * 3u;
+
+    for (; unit < unit_end; ++unit) {
+        const bool valid = mcu < n_mcu;
+        const uint32_t d[6] = {cur[0].x, cur[0].y, cur[1].x, cur[1].y, cur[2].x, cur[2].y};
+        float px[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            px[i] = (float)((d[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            asm volatile("" : "+v"(px[i]));   // from here on the floats are all there is (no second, integer copy of the bytes)
+        }
+        // the next unit's pixels are on their way while this one is worked on
+        if (unit + 1 < unit_end) {
+            bx += 8u;
+            const bool wraps = bx >= (uint32_t)blocks_w;
+            bx -= wraps ? (uint32_t)blocks_w : 0u;
+            uint32_t step = wraps ? 192u + 7u * row_bytes : 192u;
+            step = mcu + 8u < n_mcu ? step : 0u;   // lanes past the last MCU stay where they are
+            src += step;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) cur[i] = reinterpret_cast<const uint2*>(src)[i];
+        }
+
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float f[8];
+            if (mode.passthrough) {   // RGBToRGBMapper (colour_mapping.cpp:16-26): the component as it is
+#pragma unroll
+                for (int p = 0; p < 8; ++p) f[p] = px[3 * p + ch] - 128.0f;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    bool tie;
+                    f[p] = colour_forward_shifted_fast(ci[ch], px[3 * p], px[3 * p + 1], px[3 * p + 2], tie);
+                    if (__builtin_expect(__any(tie), 0)) {   // the literal formula, as in fdct_quant_kernel
+                        double ck, ca, cb, cc;
+                        colour_constants(ch, ck, ca, cb, cc);
+                        const float rounded = (float)floor(
+                            (((ck + ca * (double)px[3 * p]) + cb * (double)px[3 * p + 1]) + cc * (double)px[3 * p + 2]) + 0.5);
+                        f[p] = __builtin_amdgcn_fmed3f(rounded, 0.0f, 255.0f) - 128.0f;
+                    }
+                }
+            }
+            float o[8];
+            fdct_1d(f, o);   // row pass: o[u] = rowDCT[8u + s]
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t_write[8 * u] = o[u];
+            wave_lds_fence();
+            float in[8];
+            {
+                const float4 a = *reinterpret_cast<const float4*>(t_read), b = *reinterpret_cast<const float4*>(t_read + 4 * 66);
+                in[0] = a.x; in[1] = a.y; in[2] = a.z; in[3] = a.w;
+                in[4] = b.x; in[5] = b.y; in[6] = b.z; in[7] = b.w;
+            }
+            fdct_1d(in, o);   // column pass: o[v] = out[8v + s]
+            const float4* qrow = reinterpret_cast<const float4*>(lds_q + (mode.is_lum(ch) ? 0 : 8 * kRowQStride) + kRowQStride * s);
+#pragma unroll
+            for (int v2 = 0; v2 < 4; ++v2) {
+                const float4 c = qrow[v2];
+                *reinterpret_cast<int16_t*>(z_block + z_off[2 * v2]) = (int16_t)quantise_rn(o[2 * v2], c.x, c.y);
+                *reinterpret_cast<int16_t*>(z_block + z_off[2 * v2 + 1]) = (int16_t)quantise_rn(o[2 * v2 + 1], c.z, c.w);
+            }
+            wave_lds_fence();
+            const uint4 chunk = *reinterpret_cast<const uint4*>(z_block + 16 * s);
+            wave_lds_fence();   // the next channel's values overwrite both buffers
+            const bool nonzero = (chunk.x | chunk.y | chunk.z | chunk.w) != 0;
+            const uint64_t nz = __ballot(nonzero);
+            if (valid) {
+                if (s == 0 || nonzero) *reinterpret_cast<uint4*>(out_image + (size_t)ch * plane_bytes + out_off) = chunk;
+                if (s == 0) (mask_image + ch)[mask_off] = (uint8_t)((m < 4 ? (uint32_t)nz : (uint32_t)(nz >> 32)) >> (8 * (m & 3u)));
+            }
+        }
+        mcu += 8u;
+        out_off += 8u * 16u;
+        mask_off += 8u * 3u;
     }
 }
 
@@ -591,7 +803,23 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
     const bool fast = (width % 8 == 0) && ((reinterpret_cast<uintptr_t>(d_rgb) & 7u) == 0);
     planar = planar && d_chunk_masks != nullptr;
-#define JEA_LAUNCH_FDCT(F, P)                                                                                       \
+    if (fast && planar && bw >= 8 && height % 8 == 0 && (uint64_t)n_mcu * 384 < (1ull << 32)) {
+        // Units (8 MCUs) per wave.  Short waves suit a launch best -- workgroups then start and end at different
+        // times, so loads, arithmetic and stores of neighbours overlap and the launch has no long tail -- but a
+        // wave's set-up is worth a tenth of a unit's work.  Measured on 3840x2160 pictures (one picture / eight
+        // per launch, microseconds): 1 unit 26.3 / 178, 2 units 26.9 / 164, 4 units 27.8 / 161, 8 units 33.5 / 164.
+        // So: one unit per wave until the launch has about three rounds of resident waves (1024 SIMDs x 5), then
+        // longer waves, up to 6 units.
+        const uint64_t units = (n_mcu + 7) / 8;
+        uint64_t k64 = (units * n_images + 8192) / 16384;
+        const uint32_t best_k = (uint32_t)(k64 < 1 ? 1 : (k64 > 6 ? 6 : k64));
+        const dim3 grid_rows((unsigned)((units + (uint64_t)kRowWaves * best_k - 1) / ((uint64_t)kRowWaves * best_k)),
+                             (unsigned)n_images);
+        fdct_quant_rows_kernel<<<grid_rows, kRowThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+                                                                 d_status_to_clear, d_chunk_masks, mode, best_k);
+        return;
+    }
+#define JEA_LAUNCH_FDCT(F, P)                                                                                      \
     fdct_quant_kernel<F, P><<<grid, kFdctThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs, \
                                                           d_status_to_clear, d_chunk_masks, mode)
     if (fast && planar) JEA_LAUNCH_FDCT(true, true);

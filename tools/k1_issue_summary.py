@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Vector-instruction issue figures of the fused forward kernel -> profiles/r02_k1_issue.json.
 
-usage: k1_issue_summary.py <issue-counter pass, 1 image/launch> <issue-counter pass, 8x8 images/launch> <FETCH_SIZE pass> <WRITE_SIZE pass>
+usage: k1_issue_summary.py <issue-counter pass, 1 image/launch> <issue-counter pass, 64 images/launch> <FETCH_SIZE pass> <WRITE_SIZE pass>
 
 Dynamic counts (instructions per wave, waves, cycles) come from the rocprofv3 --pmc passes.  What share of the
 instructions issues at the full rate and what share at half of it comes from the kernel's ISA listing: the
-listing of fdct_quant_kernel<true, true> with the pass-through colour branch compiled out (it never runs for
+listing of fdct_quant_rows_kernel with the pass-through colour branch compiled out (it never runs for
 RGBToYCbCrMapper) and without the basic blocks that hold f64 instructions (the tie fall-back, run for about
 one pixel in a thousand).  Issue costs per class: tools/valu_rates.hip on this chip.
 """
@@ -35,7 +35,7 @@ def counters(directory, kernel, grid=None):
                     acc[int(r["Grid_Size"])]["_duration_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     if not acc:
         return None, {}
-    g = grid if grid in acc else max(acc)   # the grid asked for, else the largest launch
+    g = min(acc) if grid == "smallest" else max(acc)   # single-picture launches, or the largest launch
     return g, {c: sum(v) / len(v) for c, v in acc[g].items()}
 
 
@@ -50,7 +50,7 @@ def listing_classes():
                         "-fno-slp-vectorize", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "jpeg-encoder_amd", "csrc"),
                         path, "-o", out], check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
-    m = re.search(r"^(_ZN3jea12_GLOBAL__N_117fdct_quant_kernelILb1ELb1E[^\n]*):.*?\n(.*?)s_endpgm", text, re.S | re.M)
+    m = re.search(r"^(_ZN3jea12_GLOBAL__N_122fdct_quant_rows_kernelE[^\n]*):.*?\n(.*?)s_endpgm", text, re.S | re.M)
     blocks, cur = [], []
     for line in m.group(2).split("\n"):
         t = line.strip()
@@ -85,11 +85,11 @@ def listing_classes():
 
 def main():
     one_dir, many_dir, fetch_dir, write_dir = sys.argv[1:5]
-    kernel = "fdct_quant_kernel"
-    g1, c1 = counters(one_dir, kernel, 388800)
+    kernel = "fdct_quant_rows_kernel"
+    g1, c1 = counters(one_dir, kernel, "smallest")
     gm, cm = counters(many_dir, kernel)
-    _, cf = counters(fetch_dir, kernel, 388800)
-    _, cw = counters(write_dir, kernel, 388800)
+    _, cf = counters(fetch_dir, kernel, "smallest")
+    _, cw = counters(write_dir, kernel, "smallest")
     full, half, other = listing_classes()
     waves = c1["SQ_WAVES"]
     insts = c1["SQ_INSTS_VALU"] / waves
@@ -98,7 +98,7 @@ def main():
     issue_ns = insts * ((1 - share) * FULL_NS + share * HALF_NS)
     out = {
         "_how": "rocprofv3 --pmc passes over `python3 bench.py --quick --steps 20 --warmup 2 --ramp-seconds 0 --no-cpu-baseline "
-                "--streams 1` (single-image launches, grid 388800) and the same with --pool 64 --marginal-images 64 (64 images per launch in the "
+                "--streams 1` (single-image launches, the kernel's smallest grid) and the same with --pool 64 --marginal-images 64 (64 images per launch in the "
                 "roofline section); SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count in units of four cycles; "
                 "GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE doubled for gfx950 (a 128-byte request counts as 64), "
                 "both in KB; instruction classes from the ISA listing (tools/k1_issue_summary.py), issue costs from tools/valu_rates.hip",
@@ -119,7 +119,7 @@ def main():
             out["shader_clock_mhz"] = round(cycles / cm["_duration_ns"] * 1e3)
         busy = cm["SQ_INSTS_VALU"] / 1024 / cycles
         out["many_image_launch"] = {
-            "images": gm // 388800, "gui_active_cycles_per_xcd": round(cycles),
+            "images": int(round(cm["SQ_INSTS_VALU"] / c1["SQ_INSTS_VALU"])), "gui_active_cycles_per_xcd": round(cycles),
             "valu_insts_per_simd_per_cycle": round(busy, 4),
             "cycles_per_valu_inst_per_simd": round(1 / busy, 3),
             "mean_waves_per_simd": round(cm["SQ_WAVE_CYCLES"] * 4 / 1024 / cycles, 2),
