@@ -281,6 +281,18 @@ __device__ __forceinline__ void fdct_1d(const float (&in)[8], float (&out)[8]) {
     }
 }
 
+// byte s of the result: twice the zig-zag position of natural index 8 v + s
+constexpr uint64_t zigzag_row_doubled(int v) {
+    uint64_t r = 0;
+    for (int s = 0; s < 8; ++s)
+        for (int k = 0; k < 64; ++k)
+            if (kZigzag[k] == 8 * v + s) r |= (uint64_t)(2 * k) << (8 * s);
+    return r;
+}
+
+constexpr uint64_t kZigzagRowDoubled[8] = {zigzag_row_doubled(0), zigzag_row_doubled(1), zigzag_row_doubled(2), zigzag_row_doubled(3),
+                                           zigzag_row_doubled(4), zigzag_row_doubled(5), zigzag_row_doubled(6), zigzag_row_doubled(7)};
+
 // what one wave's LDS traffic must not be reordered across (the lanes exchange data with each other)
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -294,37 +306,70 @@ __global__ __launch_bounds__(kRowThreads, 4) void fdct_quant_rows_kernel(
     uint32_t units_per_wave) {
     if (status_to_clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status_to_clear = 0;
     __shared__ __align__(16) float lds_q[2 * 8 * kRowQStride];   // [table][u]{RN(1/Q), Q}[v]
-    __shared__ uint8_t lds_zpos[64];   // zig-zag position of natural index n
     __shared__ __align__(16) float lds_t[kRowWaves][kRowTWords];
     __shared__ __align__(16) uint32_t lds_z[kRowWaves][kRowZWords];
 
     const int tid = threadIdx.x;
-    if (tid < 128) {
-        // lum_t | chr_t and rlum_t | rchr_t lie side by side in QuantTables, entry 8 u + v each
-        const float* qb = reinterpret_cast<const float*>(&q);
-        float* to = lds_q + (tid >> 6) * 8 * kRowQStride + ((tid >> 3) & 7) * kRowQStride + 2 * (tid & 7);
-        to[0] = qb[256 + tid];
-        to[1] = qb[128 + tid];
-    } else if (tid < 192) {
-        lds_zpos[kZigzag[tid - 128]] = (uint8_t)(tid - 128);
-    }
-    __syncthreads();
-
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = (uint32_t)tid & 63u, m = lane >> 3, s = lane & 7u;
     const uint32_t n_units = (n_mcu + 7u) >> 3;
     uint32_t unit = ((uint32_t)blockIdx.x * kRowWaves + (uint32_t)wave) * units_per_wave;
     const uint32_t unit_end = unit + units_per_wave < n_units ? unit + units_per_wave : n_units;
-    if (unit >= unit_end) return;   // no workgroup barrier below
+    const bool has_work = unit < unit_end;   // per wave; false only in the last workgroup of a picture
 
-    const uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
-    const uint32_t t_slot = (uint32_t)kRowTSlot[m & 3u] + 128u * (m >> 2);
+    // MCU of this lane in the first unit; later units are 8 MCUs further each.  Width and height are multiples
+    // of 8 here (the launcher's condition), so a row of MCUs is a row of 24 blocks_w bytes, no row is repeated,
+    // and a lane's pixels move 192 bytes per unit, plus seven pixel rows when its MCU wraps into the next row.
+    // The first unit's pixels are asked for before anything else: every other step of the set-up hides behind them.
+    // (asked for even earlier, so that they arrive first: the two table entries this thread copies into LDS;
+    // lum_t | chr_t and rlum_t | rchr_t lie side by side in QuantTables, entry 8 u + v each)
+    float2 q_pair = make_float2(0.0f, 0.0f);
+    if (tid < 128) {
+        const float* qb = reinterpret_cast<const float*>(&q);
+        q_pair = make_float2(qb[256 + tid], qb[128 + tid]);
+    }
+    uint32_t mcu = unit * 8u + m;
+    const uint32_t row_bytes = (uint32_t)width * 3u;
+    // the tail of a picture's last unit reads the last MCU and is never stored; so does a wave without work, so
+    // that the loads are issued unconditionally and the copy of the tables need not wait for them
+    const uint32_t mcu_in = mcu < n_mcu ? mcu : n_mcu - 1u;
+    // mcu_in / blocks_w through a float quotient and one correction either way (exact: both are below 2^24, the
+    // launcher's condition; the integer division costs twice the instructions)
+    uint32_t by0 = (uint32_t)((float)mcu_in * __builtin_amdgcn_rcpf((float)blocks_w));
+    int32_t bx_signed = (int32_t)mcu_in - (int32_t)(by0 * (uint32_t)blocks_w);
+    by0 = bx_signed < 0 ? by0 - 1u : (bx_signed >= blocks_w ? by0 + 1u : by0);
+    bx_signed = bx_signed < 0 ? bx_signed + blocks_w : (bx_signed >= blocks_w ? bx_signed - blocks_w : bx_signed);
+    uint32_t bx = (uint32_t)bx_signed;
+    const uint8_t* src = rgb + (size_t)blockIdx.y * image_bytes + ((size_t)by0 * 8 + s) * row_bytes + (size_t)bx * 24;
+    uint2 cur[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cur[i] = reinterpret_cast<const uint2*>(src)[i];
+    if (tid < 128) {
+        float* to = lds_q + (tid >> 6) * 8 * kRowQStride + ((tid >> 3) & 7) * kRowQStride + 2 * (tid & 7);
+        to[0] = q_pair.x;
+        to[1] = q_pair.y;
+    }
+    __syncthreads();
+    if (!has_work) return;   // no workgroup barrier below
+
+    // kRowTSlot[m & 3] and kRowZWord[m & 3] without a table in memory
+    const uint32_t m_lo = m & 1u, m_hi = (m >> 1) & 1u;
+    const uint32_t t_slot = 40u * m_hi + (m_lo ^ m_hi) + 128u * (m >> 2);
+    const uint32_t z_word = 36u * (m_lo ^ m_hi) + 80u * m_hi + 148u * (m >> 2);
+    static_assert(kRowTSlot[0] == 0 && kRowTSlot[1] == 1 && kRowTSlot[2] == 41 && kRowTSlot[3] == 40, "layout");
+    static_assert(kRowZWord[0] == 0 && kRowZWord[1] == 36 && kRowZWord[2] == 116 && kRowZWord[3] == 80, "layout");
     float* const t_write = lds_t[wave] + 4u * (t_slot + 66u * (s >> 2)) + (s & 3u);   // + 8 u: value of frequency u, row s
     const float* const t_read = lds_t[wave] + 4u * (t_slot + 2u * s);   // rows 0-3 of frequency s; rows 4-7 66 slots on
-    uint8_t* const z_block = reinterpret_cast<uint8_t*>(lds_z[wave] + (uint32_t)kRowZWord[m & 3u] + 148u * (m >> 2));
-    uint32_t z_off[8];   // where coefficient (v, u = s) goes: its zig-zag position, two bytes each
+    uint8_t* const z_block = reinterpret_cast<uint8_t*>(lds_z[wave] + z_word);
+    // Where coefficient (v, u = s) goes: its zig-zag position, two bytes each.  The eight positions of row v,
+    // doubled, are the bytes of one 64-bit constant; the lane takes byte s.
+    uint32_t z_off[8];
+    const uint32_t pick_byte_s = 0x0c0c0c00u | s;   // byte-permute selector: byte s of the eight, zero-extended
 #pragma unroll
-    for (int v = 0; v < 8; ++v) z_off[v] = 2u * lds_zpos[8 * v + s];
+    for (int v = 0; v < 8; ++v) {
+        const uint64_t row = kZigzagRowDoubled[v];
+        z_off[v] = __builtin_amdgcn_perm((uint32_t)(row >> 32), (uint32_t)row, pick_byte_s);
+    }
 
     // colour constants of the three channels in vector registers (an operand in a scalar register halves the
     // issue rate of an FMA)
@@ -337,29 +382,6 @@ __global__ __launch_bounds__(kRowThreads, 4) void fdct_quant_rows_kernel(
         asm volatile("v_mov_b32 %0, %1" : "=v"(ci[ch].b) : "s"(ci[ch].b));
         asm volatile("v_mov_b32 %0, %1" : "=v"(ci[ch].c) : "s"(ci[ch].c));
     }
-
-    // MCU of this lane in the first unit; later units are 8 MCUs further each.  Width and height are multiples
-    // of 8 here (the launcher's condition), so a row of MCUs is a row of 24 blocks_w bytes, no row is repeated,
-    // and a lane's pixels move 192 bytes per unit, plus seven pixel rows when its MCU wraps into the next row.
-    uint32_t mcu = unit * 8u + m;
-    const uint32_t row_bytes = (uint32_t)width * 3u;
-    const uint32_t mcu_in = mcu < n_mcu ? mcu : n_mcu - 1u;   // the tail of the last unit reads the last MCU, and is never stored
-    // mcu_in / blocks_w through a float quotient and one correction either way (exact: both are below 2^24, the
-    // launcher's condition; the integer division costs twice the instructions)
-    uint32_t by0 = (uint32_t)((float)mcu_in * __builtin_amdgcn_rcpf((float)blocks_w));
-    int32_t bx_signed = (int32_t)mcu_in - (int32_t)(by0 * (uint32_t)blocks_w);
-    if (bx_signed < 0) {
-        bx_signed += blocks_w;
-        by0 -= 1u;
-    } else if (bx_signed >= blocks_w) {
-        bx_signed -= blocks_w;
-        by0 += 1u;
-    }
-    uint32_t bx = (uint32_t)bx_signed;
-    const uint8_t* src = img + ((size_t)by0 * 8 + s) * row_bytes + (size_t)bx * 24;
-    uint2 cur[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) cur[i] = reinterpret_cast<const uint2*>(src)[i];
     // Output addresses as a uniform base plus a 32-bit offset per lane (the launcher checks that a picture's
     // planes stay below 4 GiB): chunk s of channel ch of this lane's MCU, and the MCU's three mask bytes.
     const uint32_t plane_bytes = n_mcu * 16u;

@@ -85,6 +85,7 @@ def listing_classes():
 
 def main():
     one_dir, many_dir, fetch_dir, write_dir = sys.argv[1:5]
+    many_images = int(sys.argv[5]) if len(sys.argv) > 5 else 64   # images per launch in the second pass
     kernel = "fdct_quant_rows_kernel"
     g1, c1 = counters(one_dir, kernel, "smallest")
     gm, cm = counters(many_dir, kernel)
@@ -119,7 +120,7 @@ def main():
             out["shader_clock_mhz"] = round(cycles / cm["_duration_ns"] * 1e3)
         busy = cm["SQ_INSTS_VALU"] / 1024 / cycles
         out["many_image_launch"] = {
-            "images": int(round(cm["SQ_INSTS_VALU"] / c1["SQ_INSTS_VALU"])), "gui_active_cycles_per_xcd": round(cycles),
+            "images": many_images, "gui_active_cycles_per_xcd": round(cycles),
             "valu_insts_per_simd_per_cycle": round(busy, 4),
             "cycles_per_valu_inst_per_simd": round(1 / busy, 3),
             "mean_waves_per_simd": round(cm["SQ_WAVE_CYCLES"] * 4 / 1024 / cycles, 2),
