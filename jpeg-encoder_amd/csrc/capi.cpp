@@ -86,7 +86,7 @@ struct jea_ctx {
     DeviceBuffer ustream, chunk_drops, chunk_base, img_drops, sub_end, sub_used, sub_info, grp_sum, grp_base,
         round_flags, grp_pending, grp_end, sub_guess, first_bad, ctx_keys, ctx_vals, huff_hist, huff_tables, huff_spec,
         step_tables;
-    DeviceBuffer tile_ff8;
+    DeviceBuffer tile_ff8, group_flags;
     void* pin_io = nullptr;   // pinned staging for the host-buffer entry points
     size_t pin_io_bytes = 0;
     hipEvent_t piece_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -528,7 +528,7 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->sub_end, &ctx->sub_used, &ctx->sub_info, &ctx->grp_sum, &ctx->grp_base,
                             &ctx->round_flags, &ctx->grp_pending, &ctx->grp_end, &ctx->sub_guess, &ctx->first_bad, &ctx->ctx_keys,
                             &ctx->huff_hist, &ctx->huff_tables, &ctx->huff_spec, &ctx->step_tables,
-                            &ctx->ctx_vals, &ctx->tile_ff8})
+                            &ctx->ctx_vals, &ctx->tile_ff8, &ctx->group_flags})
         free_buffer(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
@@ -1391,12 +1391,19 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     if ((rc = ensure(ctx, ctx->coefs, n_images * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
     // the coefficients stay inside the library: block records and chunk planes
     if ((rc = ensure(ctx, ctx->masks, n_images * mcus * 3 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->group_flags, idct_group_list_bytes()))) return rc;
     // The inverse transform is enqueued right behind the write pass, before anything is known about the
     // stream: a decode waits for the GPU once.  So when an error is reported, d_rgb holds garbage.
     const QuantTables qt = to_float_tables(lum_q, chr_q);
+    // A block that is a DC value alone takes about a byte of the stream (a short DC code and the end-of-block
+    // code), a block with detail several: the files' sizes tell which inverse-transform route suits the batch.
+    size_t scan_bytes = 0;
+    for (size_t i = 0; i < n_images; ++i) scan_bytes += h_sizes[i] - JEA_HEADER_BYTES;
+    const bool mostly_single_colours = (double)scan_bytes < 5.0 * (double)n_images * (double)mcus;
     auto inverse = [&](const DecodeReportRelay& relay) {
         launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height, qt, d_rgb,
-                            (const uint32_t*)ctx->masks.ptr, ctx->mode, relay);
+                            (const uint32_t*)ctx->masks.ptr, ctx->mode, relay, (uint32_t*)ctx->group_flags.ptr,
+                            mostly_single_colours);
         return true;
     };
     return run_entropy_decode(ctx, d_jpeg, h_offsets, h_sizes, n_images, JEA_HEADER_BYTES, mcus,

@@ -39,6 +39,7 @@ namespace {
 
 constexpr int kMcusPerGroup = 64;
 constexpr int kFdctThreads = 192;
+constexpr uint32_t kSparseListCapacity = 32768;   // groups idct_sparse_kernel can hand to idct_dequant_kernel
 
 #ifndef JEA_K1_MIN_WAVES
 #define JEA_K1_MIN_WAVES 5
@@ -293,6 +294,17 @@ constexpr uint64_t zigzag_row_doubled(int v) {
 constexpr uint64_t kZigzagRowDoubled[8] = {zigzag_row_doubled(0), zigzag_row_doubled(1), zigzag_row_doubled(2), zigzag_row_doubled(3),
                                            zigzag_row_doubled(4), zigzag_row_doubled(5), zigzag_row_doubled(6), zigzag_row_doubled(7)};
 
+// byte v of entry u: twice the zig-zag position of natural index 8 v + u (the inverse kernel's lanes hold a row v)
+constexpr uint64_t zigzag_col_doubled(int u) {
+    uint64_t r = 0;
+    for (int v = 0; v < 8; ++v)
+        for (int k = 0; k < 64; ++k)
+            if (kZigzag[k] == 8 * v + u) r |= (uint64_t)(2 * k) << (8 * v);
+    return r;
+}
+constexpr uint64_t kZigzagColDoubled[8] = {zigzag_col_doubled(0), zigzag_col_doubled(1), zigzag_col_doubled(2), zigzag_col_doubled(3),
+                                           zigzag_col_doubled(4), zigzag_col_doubled(5), zigzag_col_doubled(6), zigzag_col_doubled(7)};
+
 // what one wave's LDS traffic must not be reordered across (the lanes exchange data with each other)
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -540,7 +552,19 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
                                                                     int height, int blocks_w, uint32_t n_mcu,
                                                                     size_t image_bytes, QuantTables q,
                                                                     uint8_t* __restrict__ rgb, ComponentMode mode,
-                                                                    DecodeReportRelay relay) {
+                                                                    DecodeReportRelay relay,
+                                                                    const uint32_t* __restrict__ group_list,
+                                                                    uint32_t groups_per_image) {
+    // Which group of 64 MCUs of which image: the grid says (x = group, y = image), or, behind idct_sparse_kernel,
+    // the list of the groups that kernel left alone does (group_list[0] = entries, then image * groups + group each).
+    uint32_t group_x = blockIdx.x, image = blockIdx.y;
+    if (group_list != nullptr) {
+        const uint32_t listed = group_list[0] < kSparseListCapacity ? group_list[0] : kSparseListCapacity;
+        if (blockIdx.x >= listed) return;
+        const uint32_t id = group_list[1 + blockIdx.x];
+        image = id / groups_per_image;
+        group_x = id - image * groups_per_image;
+    }
     // the decoder's outcome, known since the kernels before this one ended, goes to the host on the side
     if (relay.report != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         relay.report->unsettled = *relay.unsettled;
@@ -556,12 +580,12 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     __shared__ uint8_t varied[kMcusPerGroup];
 
     const int tid = threadIdx.x;
-    const uint32_t g0 = blockIdx.x * kMcusPerGroup;
-    uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
+    const uint32_t g0 = group_x * kMcusPerGroup;
+    uint8_t* img = rgb + (size_t)image * image_bytes;
     const uint32_t mcus_here = (n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup;
 
     if (!kPlanar) {
-        const uint4* in = reinterpret_cast<const uint4*>(coefs + ((size_t)blockIdx.y * n_mcu + g0) * 192);
+        const uint4* in = reinterpret_cast<const uint4*>(coefs + ((size_t)image * n_mcu + g0) * 192);
         const uint32_t n_chunks = mcus_here * 3 * 8;
         for (uint32_t i = tid; i < n_chunks; i += kFdctThreads) {
             const uint32_t jj = i >> 3, kk = i & 7u;
@@ -591,9 +615,9 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
             // lanes of a wave are consecutive 16-byte elements of a plane) into its LDS slot; chunks
             // beyond the first are not even looked at when the whole wave has none.
             const uint32_t mcu = g0 + (uint32_t)m;
-            const uint32_t rec = records[((size_t)blockIdx.y * n_mcu + mcu) * 3 + channel];
+            const uint32_t rec = records[((size_t)image * n_mcu + mcu) * 3 + channel];
             const uint32_t mask = (rec >> 16) & 0xffu;
-            const uint4* plane = reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu + mcu;
+            const uint4* plane = reinterpret_cast<const uint4*>(coefs) + ((size_t)image * 24 + channel) * n_mcu + mcu;
             rest_nonzero = (mask >> 1) != 0;
             far_nonzero = (mask >> 2) != 0;
             dc_alone = mask == 0;
@@ -783,6 +807,268 @@ __global__ __launch_bounds__(kFdctThreads) void idct_dequant_kernel(const int16_
     }
 }
 
+// ---------------------------------------------------------------------------
+// The decoder's inverse transform for groups of MCUs that are mostly single colours (smooth pictures at
+// ordinary qualities: all but two or three of a group's 64 MCUs have DC values alone).  In idct_dequant_kernel
+// every lane carries a block, so two blocks with detail cost the wave the whole transform, and its 24 KiB of
+// coefficients in LDS keep the compute units half empty.  Here:
+//   1. thread (channel, MCU) reads its block's record; a block that is its DC value alone is one sample value;
+//   2. MCUs whose three blocks are such values are one colour: converted once and stored as eight rows, from
+//      the records alone (colour_mapping.cpp:69-92, block_grid.cpp:87-99);
+//   3. the other MCUs are listed, and their blocks are transformed eight at a time per wave with the lanes laid
+//      out by block ROW (lane = 8 b + s, as in fdct_quant_rows_kernel): chunks -> LDS -> de-zigzag and dequantise
+//      a row of coefficients (entropy_encoder.cpp:79-92, quantiser.cpp:72-85) -> row pass -> transposition
+//      through LDS -> column pass, clamp, truncation (discrete_cosine_transform.cpp:126-156) -> samples to LDS;
+//      then colour conversion and store of those MCUs' rows.
+// A group with more than kSparseMaxVaried such MCUs is put on a list and left to idct_dequant_kernel, which is
+// launched behind this kernel with one workgroup per place on the list (a few in the pictures this kernel is
+// for; the launcher sends batches of detailed pictures to idct_dequant_kernel alone).  When the list is full the
+// group is done here after all, in as many passes as it takes.  Needs width % 8 == 0.
+constexpr int kSparseMaxVaried = 16;
+constexpr int kSparseTStride = 72;    // floats per block in the transposition buffer (stores of one x go to 32 different banks)
+
+// Row-lane inverse transform of eight blocks per wave on the triangle u + v <= D (D = 7: everything).
+// z_block: the block's chunks (zig-zag order) in LDS; qrow: row v of the dequantisation table;
+// out: the eight samples of column x = s, rows y = 0..7, as bytes, in two words.
+template <int D>
+__device__ __forceinline__ void idct_rowlane(const uint8_t* z_block, const uint32_t (&z_off)[8], const float* qrow,
+                                             float* t_write, const float* t_read, uint32_t (&out)[2]) {
+    constexpr int kTerms = D < 7 ? D + 1 : 8;
+    float deq[8];
+    {
+        const float4 qa = *reinterpret_cast<const float4*>(qrow), qb = *reinterpret_cast<const float4*>(qrow + 4);
+        const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+        for (int u = 0; u < kTerms; ++u)
+            deq[u] = (float)(int)*reinterpret_cast<const int16_t*>(z_block + z_off[u]) * qv[u];
+    }
+    // row pass :126-135: tmp[x][v] = sum_u (s(u)C[u][x]) * src[u + 8v]; rows beyond the triangle hold zeros
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        float acc = inv_c(0, x) * deq[0];
+#pragma unroll
+        for (int u = 1; u < kTerms; ++u) acc += inv_c(u, x) * deq[u];
+        t_write[8 * x] = acc;
+    }
+    wave_lds_fence();
+    float in[8];
+    {
+        const float4 a = *reinterpret_cast<const float4*>(t_read), b = *reinterpret_cast<const float4*>(t_read + 4);
+        in[0] = a.x; in[1] = a.y; in[2] = a.z; in[3] = a.w;
+        in[4] = b.x; in[5] = b.y; in[6] = b.z; in[7] = b.w;
+    }
+    wave_lds_fence();
+    // column pass :136-156, then + 128 (:21-27); the byte conversion saturates as the clamp of :144-154 does
+    out[0] = out[1] = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        float acc = inv_c(0, y) * in[0];
+#pragma unroll
+        for (int v = 1; v < kTerms; ++v) acc += inv_c(v, y) * in[v];
+        out[y >> 2] = insert_byte(__builtin_truncf(acc) + 128.0f, y & 3, out[y >> 2]);
+    }
+}
+
+__global__ __launch_bounds__(kFdctThreads, 6) void idct_sparse_kernel(const int16_t* __restrict__ coefs,
+                                                                       const uint32_t* __restrict__ records, int width,
+                                                                       int height, int blocks_w, uint32_t n_mcu,
+                                                                       size_t image_bytes, QuantTables q,
+                                                                       uint8_t* __restrict__ rgb, ComponentMode mode,
+                                                                       DecodeReportRelay relay,
+                                                                       uint32_t* __restrict__ group_list) {
+    // the decoder's outcome, known since the kernels before this one ended, goes to the host on the side
+    if (relay.report != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        relay.report->unsettled = *relay.unsettled;
+        relay.report->status = *relay.status;
+    }
+    __shared__ uint8_t lds_dc[3 * kMcusPerGroup];    // sample value of a block that is its DC value alone
+    __shared__ uint32_t lds_rec[3 * kMcusPerGroup];  // the group's records, [channel][MCU]
+    __shared__ __align__(16) uint4 lds_first[3 * kMcusPerGroup];   // first chunk of the blocks that have one stored
+    __shared__ uint64_t dc_alone_of[3];
+    __shared__ uint8_t varied[kMcusPerGroup];
+    __shared__ __align__(16) float lds_qt[128];      // dequantisation tables, natural order: luminance | chrominance
+    __shared__ __align__(16) float lds_t[3][8 * kSparseTStride];
+    __shared__ __align__(16) uint32_t lds_z[3][kRowZWords];
+    __shared__ __align__(16) uint8_t lds_px[3 * 8 * 64];   // samples of the eight MCUs of a pass, [channel][b][y][x]
+
+    const int tid = threadIdx.x;
+    const uint32_t g0 = blockIdx.x * kMcusPerGroup;
+    uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
+    const uint32_t mcus_here = (n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup;
+    const int channel = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lane = (uint32_t)tid & 63u;
+    const uint32_t* rec_image = records + (size_t)blockIdx.y * n_mcu * 3;
+
+    {
+        const bool valid = lane < mcus_here;
+        const uint32_t rec = valid ? rec_image[(g0 + lane) * 3 + channel] : 0u;
+        if (tid < 128) lds_qt[tid] = reinterpret_cast<const float*>(&q)[tid];
+        const float q0 = mode.is_lum(channel) ? q.lum[0] : q.chr[0];
+        // DC alone: every sample is s(0)C[0][y] * (s(0)C[0][x] * deq[0]) with C[0][.] = 1, clamped and truncated (:144-154)
+        const float dc_only = inv_c(0, 0) * (inv_c(0, 0) * ((float)(int)(int16_t)(rec & 0xffffu) * q0));
+        lds_dc[channel * kMcusPerGroup + lane] = (uint8_t)((int)__builtin_amdgcn_fmed3f(dc_only, -128.0f, 127.0f) + 128);
+        const uint64_t alone = __ballot(valid && ((rec >> 16) & 0xffu) == 0);
+        if (lane == 0) dc_alone_of[channel] = alone;
+        // what the transform of the listed MCUs will want is asked for now, so that it is there by then: the
+        // record goes to LDS, and so does the first chunk of a block that has one (few lanes; later chunks are rare
+        // in the pictures this kernel is for and are fetched when they are needed)
+        lds_rec[channel * kMcusPerGroup + lane] = rec;
+        if ((rec >> 16) & 1u)
+            lds_first[channel * kMcusPerGroup + lane] =
+                (reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu)[g0 + lane];
+    }
+    __syncthreads();
+    const uint64_t flat = dc_alone_of[0] & dc_alone_of[1] & dc_alone_of[2];
+    const uint32_t n_varied = mcus_here - (uint32_t)__popcll(flat);
+    if (n_varied > (uint32_t)kSparseMaxVaried) {   // for idct_dequant_kernel, if the list has room
+        __shared__ uint32_t place;
+        if (tid == 0) {
+            place = atomicAdd(group_list, 1u);
+            if (place < kSparseListCapacity) group_list[1 + place] = blockIdx.y * gridDim.x + blockIdx.x;
+        }
+        __syncthreads();
+        if (place < kSparseListCapacity) return;
+    }
+    if (channel == 0 && lane < mcus_here && !((flat >> lane) & 1u)) {
+        const uint64_t others = ~flat;
+        varied[__builtin_amdgcn_mbcnt_hi((uint32_t)(others >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)others, 0u))] = (uint8_t)lane;
+    }
+    {
+        // One colour: thread t takes MCU t / 3 and the 8-byte piece t % 3 of its 24-byte rows, so that the lanes of
+        // a wave write consecutive bytes.
+        const uint32_t fm = (uint32_t)tid / 3u, piece = (uint32_t)tid - 3u * fm;
+        if ((flat >> fm) & 1u) {
+            const uint32_t mcu = g0 + fm;
+            const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
+            const int c0 = lds_dc[fm], c1 = lds_dc[kMcusPerGroup + fm], c2 = lds_dc[2 * kMcusPerGroup + fm];
+            float px3[3];
+            if (mode.passthrough) {
+                px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
+            } else {
+                bool tie;
+                colour_inverse_fast_unclamped((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);
+                if (tie) {   // the literal formula
+                    uint8_t rr, gg, bb;
+                    colour_inverse(c0, c1, c2, rr, gg, bb);
+                    px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
+                }
+            }
+            // eight pixels are the 24 bytes RGBR GBRG BRGB RGBR GBRG BRGB; piece p starts at byte 8 p, with colour 2 p mod 3
+            uint32_t w2[2] = {0, 0};
+#pragma unroll
+            for (int byte = 0; byte < 8; ++byte) {
+                const uint32_t c = (2u * piece + (uint32_t)byte) % 3u;
+                w2[byte >> 2] = insert_byte(c == 0 ? px3[0] : (c == 1 ? px3[1] : px3[2]), byte & 3, w2[byte >> 2]);
+            }
+            uint8_t* to = img + ((size_t)by * 8 * width + (size_t)bx * 8) * 3 + 8 * piece;
+            const int rows = height - (int)by * 8 < 8 ? height - (int)by * 8 : 8;
+            for (int r = 0; r < rows; ++r) *reinterpret_cast<uint2*>(to + (size_t)r * width * 3) = make_uint2(w2[0], w2[1]);
+        }
+    }
+    if (n_varied == 0) return;
+    __syncthreads();   // the list is complete
+
+    // the listed MCUs, eight per pass: wave = channel, lane = 8 b + s
+    const uint32_t b = lane >> 3, s = lane & 7u;
+    const uint32_t b_lo = b & 1u, b_hi = (b >> 1) & 1u;
+    uint8_t* const z_block = reinterpret_cast<uint8_t*>(lds_z[channel] + 36u * (b_lo ^ b_hi) + 80u * b_hi + 148u * (b >> 2));
+    float* const t_write = lds_t[channel] + b * kSparseTStride + s;        // + 8 x: value (x, row v = s)
+    const float* const t_read = lds_t[channel] + b * kSparseTStride + 8 * s;   // + v: value (x = s, row v)
+    const float* const qrow = lds_qt + (mode.is_lum(channel) ? 0 : 64) + 8 * s;
+    uint32_t z_off[8];   // byte offset of coefficient (v = s, u) in the block's zig-zag order
+    {
+        const uint32_t pick_byte_s = 0x0c0c0c00u | s;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t col = kZigzagColDoubled[u];
+            z_off[u] = __builtin_amdgcn_perm((uint32_t)(col >> 32), (uint32_t)col, pick_byte_s);
+        }
+    }
+    const uint4* plane_image = reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu;
+    for (uint32_t first = 0; first < n_varied; first += 8) {
+        const uint32_t n_here = n_varied - first < 8u ? n_varied - first : 8u;
+        const bool live = b < n_here;
+        const uint32_t mm = varied[live ? first + b : first];
+        const uint32_t mcu = g0 + mm;
+        const uint32_t rec = lds_rec[channel * kMcusPerGroup + mm];
+        const uint32_t mask = live ? (rec >> 16) & 0xffu : 0u;
+        const bool have = (mask >> s) & 1u;
+        uint4 chunk = make_uint4(0, 0, 0, 0);
+        if (have) {
+            if (s == 0) chunk = lds_first[channel * kMcusPerGroup + mm];
+            else chunk = plane_image[(size_t)s * 3 * n_mcu + mcu];
+        }
+        if (s == 0 && !have) chunk.x = rec & 0xffffu;   // no stored first chunk: the DC value from the record
+        *reinterpret_cast<uint4*>(z_block + 16 * s) = chunk;
+        // how far along the zig-zag do the coefficients of the wave's eight blocks reach?  (chunk 0: positions 0-7
+        // = diagonals u + v <= 3, words 0-1 | 2-3 | 4-5 | 6-7 on diagonals 0,1 | 1,2 | 2,2 | 3,3; chunk 1: <= 5)
+        int diag;
+        if (__ballot(have && s >= 2) != 0) diag = 7;
+        else if (__ballot(have && s == 1) != 0) diag = 5;
+        else if (__ballot(s == 0 && chunk.w != 0) != 0) diag = 3;
+        else if (__ballot(s == 0 && (chunk.y | chunk.z) != 0) != 0) diag = 2;
+        else diag = 1;
+        wave_lds_fence();
+        uint32_t col8[2];
+        switch (diag) {
+            case 1: idct_rowlane<1>(z_block, z_off, qrow, t_write, t_read, col8); break;
+            case 2: idct_rowlane<2>(z_block, z_off, qrow, t_write, t_read, col8); break;
+            case 3: idct_rowlane<3>(z_block, z_off, qrow, t_write, t_read, col8); break;
+            case 5: idct_rowlane<5>(z_block, z_off, qrow, t_write, t_read, col8); break;
+            default: idct_rowlane<7>(z_block, z_off, qrow, t_write, t_read, col8); break;
+        }
+        // column x = s of block b: bytes y = 0..7 go to [channel][b][y][x]
+        {
+            uint8_t* to = lds_px + ((uint32_t)channel * 8u + b) * 64u + s;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) to[8 * y] = (uint8_t)(col8[y >> 2] >> (8 * (y & 3)));
+        }
+        __syncthreads();
+        // colour conversion and store: work item = (row r, MCU bi of the pass) = 8 pixels = 24 contiguous bytes
+        if ((uint32_t)tid < 8u * n_here) {
+            const uint32_t r = (uint32_t)tid / n_here, bi = (uint32_t)tid - r * n_here;
+            const uint32_t mcu2 = g0 + varied[first + bi];
+            const uint32_t by = mcu2 / (uint32_t)blocks_w, bx = mcu2 - by * (uint32_t)blocks_w;
+            const int y = (int)by * 8 + (int)r;
+            if (y < height) {
+                const uint2 y8 = *reinterpret_cast<const uint2*>(lds_px + (0 * 8 + bi) * 64 + r * 8);
+                const uint2 b8 = *reinterpret_cast<const uint2*>(lds_px + (1 * 8 + bi) * 64 + r * 8);
+                const uint2 r8 = *reinterpret_cast<const uint2*>(lds_px + (2 * 8 + bi) * 64 + r * 8);
+                const uint32_t yy[2] = {y8.x, y8.y}, cbb[2] = {b8.x, b8.y}, crr[2] = {r8.x, r8.y};
+                uint32_t out[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int sh = 8 * (p & 3);
+                    const int c0 = (int)((yy[p >> 2] >> sh) & 0xffu), c1 = (int)((cbb[p >> 2] >> sh) & 0xffu),
+                              c2 = (int)((crr[p >> 2] >> sh) & 0xffu);
+                    float px3[3];
+                    if (mode.passthrough) {   // colour_mapping.cpp:28-37
+                        px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
+                    } else {
+                        bool tie;
+                        colour_inverse_fast_unclamped((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);   // insert_byte clamps
+                        if (tie) {   // the literal formula
+                            uint8_t rr, gg, bb;
+                            colour_inverse(c0, c1, c2, rr, gg, bb);
+                            px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int byte = 3 * p + c;
+                        out[byte >> 2] = insert_byte(px3[c], byte & 3, out[byte >> 2]);
+                    }
+                }
+                uint2* dst = reinterpret_cast<uint2*>(img + ((size_t)y * width + (size_t)bx * 8) * 3);
+                dst[0] = make_uint2(out[0], out[1]);
+                dst[1] = make_uint2(out[2], out[3]);
+                dst[2] = make_uint2(out[4], out[5]);
+            }
+        }
+        if (first + 8 < n_varied) __syncthreads();   // the next pass overwrites the samples
+    }
+}
+
 __global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, size_t n, uint8_t* __restrict__ ycc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t ri = rgb[3 * i], gi = rgb[3 * i + 1], bi = rgb[3 * i + 2];
@@ -853,18 +1139,34 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
 
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
                          const QuantTables& q, uint8_t* d_rgb, const uint32_t* d_records, ComponentMode mode,
-                         const DecodeReportRelay& relay) {
+                         const DecodeReportRelay& relay, uint32_t* d_group_list, bool mostly_single_colours) {
     const int bw = (width + 7) / 8, bh = (height + 7) / 8;
     const uint32_t n_mcu = (uint32_t)bw * (uint32_t)bh;
     const size_t image_bytes = (size_t)3 * width * height;
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
-    if (d_records != nullptr)
+    const uint64_t total_groups = (uint64_t)grid.x * n_images;
+    // The two-kernel route is for batches of smooth pictures: it pays off once the launch fills the GPU several
+    // times over (a single picture is quicker through the general kernel alone: one launch less in a chain
+    // that the host waits for), and only where most MCUs are single colours.
+    if (d_records != nullptr && d_group_list != nullptr && mostly_single_colours && width % 8 == 0 &&
+        total_groups >= 8192 && total_groups < (1ull << 32)) {
+        (void)hipMemsetAsync(d_group_list, 0, sizeof(uint32_t), s);
+        idct_sparse_kernel<<<grid, kFdctThreads, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu, image_bytes, q,
+                                                         d_rgb, mode, relay, d_group_list);
+        const dim3 grid_listed((unsigned)(total_groups < kSparseListCapacity ? total_groups : kSparseListCapacity), 1);
+        idct_dequant_kernel<true><<<grid_listed, kFdctThreads, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu,
+                                                                       image_bytes, q, d_rgb, mode, DecodeReportRelay{},
+                                                                       d_group_list, grid.x);
+    } else if (d_records != nullptr) {
         idct_dequant_kernel<true><<<grid, kFdctThreads, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu,
-                                                                image_bytes, q, d_rgb, mode, relay);
-    else
+                                                                image_bytes, q, d_rgb, mode, relay, nullptr, grid.x);
+    } else {
         idct_dequant_kernel<false><<<grid, kFdctThreads, 0, s>>>(d_coefs, nullptr, width, height, bw, n_mcu,
-                                                                 image_bytes, q, d_rgb, mode, relay);
+                                                                 image_bytes, q, d_rgb, mode, relay, nullptr, grid.x);
+    }
 }
+
+size_t idct_group_list_bytes() { return sizeof(uint32_t) * (1 + (size_t)kSparseListCapacity); }
 
 void launch_rgb_to_ycbcr(hipStream_t s, const uint8_t* d_rgb, size_t n_pixels, uint8_t* d_ycc) {
     const unsigned grid = (unsigned)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);

@@ -316,9 +316,14 @@ hipError_t repair_entropy_decode(hipStream_t s, const uint64_t* d_sizes, const D
 // (zig-zag positions 8c..8c+7) has a non-zero coefficient; bit 0: one of positions 1..7 is non-zero (the
 // stored chunk 0 repeats the DC value).  A block without AC coefficients is its record and nothing else:
 // one 4-byte store for the decoder instead of a chunk and a mask byte.
+// d_group_list (decoder's layout only; may be null): idct_group_list_bytes() bytes of scratch.  With it, and when the
+// caller expects most MCUs to be single colours (DC values alone: smooth pictures at ordinary qualities), groups of 64
+// MCUs that are mostly such MCUs are done by a kernel made for them and only the others by the general one.
 void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images, int width, int height,
                          const QuantTables& q, uint8_t* d_rgb, const uint32_t* d_records = nullptr,
-                         ComponentMode mode = ComponentMode{}, const DecodeReportRelay& relay = DecodeReportRelay{});
+                         ComponentMode mode = ComponentMode{}, const DecodeReportRelay& relay = DecodeReportRelay{},
+                         uint32_t* d_group_list = nullptr, bool mostly_single_colours = false);
+size_t idct_group_list_bytes();
 
 // Per-block (component granularity) launchers, blocks.hip.
 void launch_dct_forward_blocks(hipStream_t s, const uint8_t* d_in, size_t n, float* d_out);
