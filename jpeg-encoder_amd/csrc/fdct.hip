@@ -15,11 +15,10 @@
 // This file must be compiled with -ffp-contract=off.
 //
 // Two forward kernels share the arithmetic (dct_device.h).
-// fdct_quant_rows_kernel -- the fused encode's kernel for pictures whose sides are multiples of 8 (chunk-planar
-// output): lane = one pixel row / one column of a block, the block's values change hands inside the wave through
-// LDS; see the comment above it.
-// fdct_quant_kernel -- every other case (ragged sides, the [mcu][channel][64] layout of the stage-level entry
-// points and of stripes): a workgroup of 192 threads owns 64 consecutive MCUs.
+// fdct_quant_rows_kernel -- pictures whose sides are multiples of 8 (both output layouts): lane = one pixel row /
+// one column of a block, the block's values change hands inside the wave through LDS; see the comment above it.
+// fdct_quant_kernel -- every other case (ragged sides, rows of fewer than 8 MCUs): a workgroup of 192 threads
+// owns 64 consecutive MCUs.
 // Wave w (64 lanes) is channel w (Y, Cb, Cr) and lane l is MCU l, so channel
 // dependent constants are wave-uniform (scalar registers) and one thread carries
 // one whole 8x8 block-channel in registers through both DCT passes -- no
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(kFdctThreads, JEA_K1_MIN_WAVES) void fdct_quant_ker
 }
 
 // ---------------------------------------------------------------------------
-// The forward kernel of the fused encode for pictures whose width is a multiple of 8: the same arithmetic, laid
+// The forward kernel for pictures whose sides are multiples of 8 (rows of at least 8 MCUs): the same arithmetic, laid
 // out over the lanes by block ROW instead of by block.
 //
 // A wave works on 8 consecutive MCUs at a time (a "unit").  Lane l = 8 m + s: m is the MCU; s is, in turn, the
@@ -312,6 +311,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool kPlanar>
 __global__ __launch_bounds__(kRowThreads, 4) void fdct_quant_rows_kernel(
     const uint8_t* __restrict__ rgb, int width, int height, int blocks_w, uint32_t n_mcu, size_t image_bytes, QuantTables q,
     int16_t* __restrict__ coefs, int32_t* __restrict__ status_to_clear, uint8_t* __restrict__ chunk_masks, ComponentMode mode,
@@ -396,10 +396,13 @@ __global__ __launch_bounds__(kRowThreads, 4) void fdct_quant_rows_kernel(
     }
     // Output addresses as a uniform base plus a 32-bit offset per lane (the launcher checks that a picture's
     // planes stay below 4 GiB): chunk s of channel ch of this lane's MCU, and the MCU's three mask bytes.
+    // (kPlanar: the chunk planes of the fused encode, chunk 0 and non-zero chunks only; else [mcu][channel][64],
+    // every chunk, and the mask bytes only if the caller wants them)
     const uint32_t plane_bytes = n_mcu * 16u;
     uint8_t* const out_image = reinterpret_cast<uint8_t*>(coefs) + (size_t)blockIdx.y * 24 * plane_bytes;
     uint8_t* const mask_image = chunk_masks + (size_t)blockIdx.y * n_mcu * 3;
-    uint32_t out_off = s * 3u * plane_bytes + mcu * 16u, mask_off = mcu * 3u;
+    const uint32_t channel_step = kPlanar ? plane_bytes : 128u;
+    uint32_t out_off = kPlanar ? s * 3u * plane_bytes + mcu * 16u : mcu * 384u + 16u * s, mask_off = mcu * 3u;
 
     for (; unit < unit_end; ++unit) {
         const bool valid = mcu < n_mcu;
@@ -467,12 +470,13 @@ __global__ __launch_bounds__(kRowThreads, 4) void fdct_quant_rows_kernel(
             const bool nonzero = (chunk.x | chunk.y | chunk.z | chunk.w) != 0;
             const uint64_t nz = __ballot(nonzero);
             if (valid) {
-                if (s == 0 || nonzero) *reinterpret_cast<uint4*>(out_image + (size_t)ch * plane_bytes + out_off) = chunk;
-                if (s == 0) (mask_image + ch)[mask_off] = (uint8_t)((m < 4 ? (uint32_t)nz : (uint32_t)(nz >> 32)) >> (8 * (m & 3u)));
+                if (!kPlanar || s == 0 || nonzero) *reinterpret_cast<uint4*>(out_image + (size_t)ch * channel_step + out_off) = chunk;
+                if (s == 0 && (kPlanar || chunk_masks != nullptr))
+                    (mask_image + ch)[mask_off] = (uint8_t)((m < 4 ? (uint32_t)nz : (uint32_t)(nz >> 32)) >> (8 * (m & 3u)));
             }
         }
         mcu += 8u;
-        out_off += 8u * 16u;
+        out_off += kPlanar ? 8u * 16u : 8u * 384u;
         mask_off += 8u * 3u;
     }
 }
@@ -1111,7 +1115,7 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
     const dim3 grid((n_mcu + kMcusPerGroup - 1) / kMcusPerGroup, (unsigned)n_images);
     const bool fast = (width % 8 == 0) && ((reinterpret_cast<uintptr_t>(d_rgb) & 7u) == 0);
     planar = planar && d_chunk_masks != nullptr;
-    if (fast && planar && bw >= 8 && height % 8 == 0 && (uint64_t)n_mcu * 384 < (1ull << 32)) {
+    if (fast && bw >= 8 && height % 8 == 0 && (uint64_t)n_mcu * 384 < (1ull << 32)) {
         // Units (8 MCUs) per wave.  Short waves suit a launch best -- workgroups then start and end at different
         // times, so loads, arithmetic and stores of neighbours overlap and the launch has no long tail -- but a
         // wave's set-up is worth a tenth of a unit's work.  Measured on 3840x2160 pictures (one picture / eight
@@ -1120,11 +1124,20 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
         // longer waves, up to 6 units.
         const uint64_t units = (n_mcu + 7) / 8;
         uint64_t k64 = (units * n_images + 8192) / 16384;
+#ifdef JEA_K1_UNITS   // experiments: tools/build_variant.sh <name> -DJEA_K1_UNITS=<n>
+        const uint32_t best_k = JEA_K1_UNITS;
+        (void)k64;
+#else
         const uint32_t best_k = (uint32_t)(k64 < 1 ? 1 : (k64 > 6 ? 6 : k64));
+#endif
         const dim3 grid_rows((unsigned)((units + (uint64_t)kRowWaves * best_k - 1) / ((uint64_t)kRowWaves * best_k)),
                              (unsigned)n_images);
-        fdct_quant_rows_kernel<<<grid_rows, kRowThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
-                                                                 d_status_to_clear, d_chunk_masks, mode, best_k);
+        if (planar)
+            fdct_quant_rows_kernel<true><<<grid_rows, kRowThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+                                                                           d_status_to_clear, d_chunk_masks, mode, best_k);
+        else
+            fdct_quant_rows_kernel<false><<<grid_rows, kRowThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+                                                                            d_status_to_clear, d_chunk_masks, mode, best_k);
         return;
     }
 #define JEA_LAUNCH_FDCT(F, P)                                                                                      \

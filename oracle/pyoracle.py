@@ -257,3 +257,13 @@ def dequantise_blocks(q_i16, table):
     for i in range(a.shape[0]):
         LIB.jo_dequantise(a[i].ctypes.data, _p(table), out[i].ctypes.data)
     return out
+
+
+def _build_tables_once():
+    """The C library builds its cosine, Huffman and decode tables on first use, without a lock: one encode and one
+    decode here, on the importing thread, so that callers may use the functions above from several threads."""
+    tiny = gen_image(8, 8, 0, 1)
+    decode(encode(tiny, 50), 8, 8, 50)
+
+
+_build_tables_once()

@@ -50,7 +50,7 @@ def listing_classes():
                         "-fno-slp-vectorize", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "jpeg-encoder_amd", "csrc"),
                         path, "-o", out], check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
-    m = re.search(r"^(_ZN3jea12_GLOBAL__N_122fdct_quant_rows_kernelE[^\n]*):.*?\n(.*?)s_endpgm", text, re.S | re.M)
+    m = re.search(r"^(_ZN3jea12_GLOBAL__N_122fdct_quant_rows_kernelILb1E[^\n]*):.*?\n(.*?)s_endpgm", text, re.S | re.M)
     blocks, cur = [], []
     for line in m.group(2).split("\n"):
         t = line.strip()
