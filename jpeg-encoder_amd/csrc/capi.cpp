@@ -1395,11 +1395,16 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     // The inverse transform is enqueued right behind the write pass, before anything is known about the
     // stream: a decode waits for the GPU once.  So when an error is reported, d_rgb holds garbage.
     const QuantTables qt = to_float_tables(lum_q, chr_q);
-    // A block that is a DC value alone takes about a byte of the stream (a short DC code and the end-of-block
-    // code), a block with detail several: the files' sizes tell which inverse-transform route suits the batch.
-    size_t scan_bytes = 0;
-    for (size_t i = 0; i < n_images; ++i) scan_bytes += h_sizes[i] - JEA_HEADER_BYTES;
-    const bool mostly_single_colours = (double)scan_bytes < 5.0 * (double)n_images * (double)mcus;
+    // Which inverse-transform route suits the batch is read from the files' sizes.  An MCU of one colour takes
+    // 1.75 to about 2.2 bytes of the stream (three short DC codes, three end-of-block codes), one with detail more.
+    // Measured on batches of 256 smooth 1080p frames (the two-kernel route against the general kernel, us):
+    // q=25 1.83 B/MCU 352 / 447, q=50 1.90 B 501 / 593, q=60 1.99 B 560 / 703 -- but q=75 2.74 B 1812 / 1026 and
+    // q=85 4.99 B 1894 / 1296, where most groups of 64 MCUs hold more than 16 MCUs with detail.  An average says
+    // little (a few noise frames among smooth ones lift it past 2.7): nine files in ten must be under 2.2 B/MCU.
+    size_t small_files = 0;
+    for (size_t i = 0; i < n_images; ++i)
+        small_files += (double)(h_sizes[i] - JEA_HEADER_BYTES) < 2.2 * (double)mcus;
+    const bool mostly_single_colours = small_files * 10 >= n_images * 9;
     auto inverse = [&](const DecodeReportRelay& relay) {
         launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height, qt, d_rgb,
                             (const uint32_t*)ctx->masks.ptr, ctx->mode, relay, (uint32_t*)ctx->group_flags.ptr,

@@ -1161,6 +1161,9 @@ void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images,
     // The two-kernel route is for batches of smooth pictures: it pays off once the launch fills the GPU several
     // times over (a single picture is quicker through the general kernel alone: one launch less in a chain
     // that the host waits for), and only where most MCUs are single colours.
+#ifdef JEA_NO_SPARSE   // experiments: the general kernel alone
+    mostly_single_colours = false;
+#endif
     if (d_records != nullptr && d_group_list != nullptr && mostly_single_colours && width % 8 == 0 &&
         total_groups >= 8192 && total_groups < (1ull << 32)) {
         (void)hipMemsetAsync(d_group_list, 0, sizeof(uint32_t), s);

@@ -121,10 +121,10 @@ def test_c5_decode_of_1024_frames_in_one_call(ctx, po, jea, frames):
 
 
 def test_decode_batch_whose_detailed_groups_overflow_the_inverse_transforms_list(ctx, po, jea):
-    """A batch that the files' sizes send to the inverse kernel for single-colour groups (under 5 bytes of scan per MCU
-    on average) but that holds more groups with detail (507 per textured frame) than that kernel's list for the general
-    kernel has places (32 768): the groups that find the list full are transformed by the first kernel itself.
-    Two distinct sources, many copies: every decoded copy must equal the oracle's decode of its source."""
+    """A batch that the files' sizes send to the inverse kernel for single-colour groups (nine files in ten under 2.2
+    bytes of scan per MCU) but that holds more groups with detail (507 per textured frame) than that kernel's list for
+    the general kernel has places (32 768): the groups that find the list full are transformed by the first kernel
+    itself.  Two distinct sources, many copies: every decoded copy must equal the oracle's decode of its source."""
     import torch
 
     q = 50
@@ -142,16 +142,14 @@ def test_decode_batch_whose_detailed_groups_overflow_the_inverse_transforms_list
     mcus = (FW // 8) * (FH // 8)
     per_mcu = [(len(f) - 607) / mcus for f in files]
     n_textured = 32768 // 507 + 4                        # 68 frames: 34 476 groups with detail
-    assert per_mcu[0] < 4.0 < per_mcu[1], per_mcu
-    n_smooth = int(np.ceil(n_textured * (per_mcu[1] - 4.5) / (4.5 - per_mcu[0])))
-    assert n_smooth < 3000, per_mcu
-    n = n_smooth + n_textured
+    assert per_mcu[0] < 2.2 < per_mcu[1], per_mcu
+    n = 10 * n_textured + 8                              # the textured frames are under a tenth of the batch
     kind = np.zeros(n, dtype=np.int64)
     kind[np.linspace(0, n - 1, n_textured).astype(np.int64)] = 1      # the textured frames spread over the batch
     padded = [f + bytes(-len(f) % 64) for f in files]
     sizes = np.array([len(files[k]) for k in kind], dtype=np.uint64)
     offs = np.concatenate([[0], np.cumsum([len(padded[k]) for k in kind])[:-1]]).astype(np.uint64)
-    assert float(sizes.sum() - 607 * n) < 5.0 * n * mcus            # the route under test is the one taken
+    assert 10 * int((sizes - 607 < 2.2 * mcus).sum()) >= 9 * n        # the route under test is the one taken
     d_jpeg = ctx.to_device(np.frombuffer(b"".join(padded[k] for k in kind), np.uint8))
     rgb = ctx.decode_batch(d_jpeg, offs, sizes, FW, FH, lum, chrom).view(n, FH, FW, 3)
     wrong = [i for i in range(n) if not torch.equal(rgb[i], want[kind[i]].view(FH, FW, 3))]
