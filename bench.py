@@ -409,10 +409,19 @@ def config_c2(job):
                             "measured_issue_ns_full_rate": VALU_FULL_RATE_NS, "measured_issue_ns_half_rate": VALU_HALF_RATE_NS,
                             "half_rate_share_of_insts": pmc.get("half_rate_share"),
                             "issue_frac_single_launch": round(pmc["issue_ns_per_wave"] * waves / SIMDS / (one_ms * 1e6), 4),
-                            "shader_clock_mhz_under_load": pmc.get("shader_clock_mhz")}
+                            "shader_clock_mhz_under_load": pmc.get("shader_clock_mhz"),
+                            "issue_frac_note": "issue time by the per-instruction costs of a microbenchmark (tools/valu_rates.hip, "
+                                               "taken at 2.30 GHz) over the measured time; the shader clock moves between 1.8 and "
+                                               "2.3 GHz with the load, so a value near 1, or a little above, reads: at the issue bound"}
         if "marginal_us_per_step_of_work" in roofline:
+            # a wave of a large launch does several units of work and pays its set-up once: fewer instructions per
+            # image than in a single-image launch (counted in the 64-image pass of the same profile)
+            many = pmc.get("counters_many_image_launch", {}).get("SQ_INSTS_VALU")
+            images = pmc.get("many_image_launch", {}).get("images")
+            insts_image = many / images if many and images else insts * waves
+            roofline["valu"]["insts_per_image_in_large_launches"] = round(insts_image)
             roofline["valu"]["issue_frac_marginal"] = round(
-                pmc["issue_ns_per_wave"] * waves / SIMDS / (roofline["marginal_us_per_step_of_work"] * 1e3), 4)
+                pmc["issue_ns_per_wave"] / insts * insts_image / SIMDS / (roofline["marginal_us_per_step_of_work"] * 1e3), 4)
     # in the pipeline: phase durations of whole encodes (events between the kernels of one context)
     ctx.set_profiling(True)
     o = dict(out=torch.empty(capacity(args.mode), dtype=torch.uint8, device=job.dev), offsets=torch.zeros(batch, dtype=torch.int64, device=job.dev),
