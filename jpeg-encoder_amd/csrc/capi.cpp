@@ -1401,9 +1401,12 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     // q=25 1.83 B/MCU 352 / 447, q=50 1.90 B 501 / 593, q=60 1.99 B 560 / 703 -- but q=75 2.74 B 1812 / 1026 and
     // q=85 4.99 B 1894 / 1296, where most groups of 64 MCUs hold more than 16 MCUs with detail.  An average says
     // little (a few noise frames among smooth ones lift it past 2.7): nine files in ten must be under 2.2 B/MCU.
+    // (With the pass-through mapper all three components use the luminance codes, whose end-of-block code is two
+    // bits longer than the chrominance one: 2.25 to about 2.8 bytes for an MCU of one colour.)
+    const double small_limit = ctx->mode.passthrough ? 2.8 : 2.2;
     size_t small_files = 0;
     for (size_t i = 0; i < n_images; ++i)
-        small_files += (double)(h_sizes[i] - JEA_HEADER_BYTES) < 2.2 * (double)mcus;
+        small_files += (double)(h_sizes[i] - JEA_HEADER_BYTES) < small_limit * (double)mcus;
     const bool mostly_single_colours = small_files * 10 >= n_images * 9;
     auto inverse = [&](const DecodeReportRelay& relay) {
         launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height, qt, d_rgb,

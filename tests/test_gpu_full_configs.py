@@ -156,3 +156,43 @@ def test_decode_batch_whose_detailed_groups_overflow_the_inverse_transforms_list
     del rgb, d_jpeg
     torch.cuda.empty_cache()
     assert not wrong, (len(wrong), wrong[:8])
+
+
+@pytest.mark.parametrize("mapper", [0, 1])
+def test_decode_batch_of_many_small_smooth_pictures_with_both_mappers(po, jea, mapper):
+    """Thousands of small pictures in one call reach the inverse kernel for single-colour groups (8192 groups of 64
+    MCUs, small files) too -- with the YCbCr mapper and with the pass-through mapper (colour_mapping.cpp:16-42), and
+    with a last group of each picture that is not full (120 MCUs: groups of 64 and 56)."""
+    import torch
+
+    w, h, q, n = 120, 64, 50, 4200
+    lum, chrom = jea.binding.quant_tables(q)
+    ctx = jea.Context(0)
+    try:
+        ctx.set_colour_mapper(mapper)
+        po.set_mapper(mapper)
+        flat = np.empty((h, w, 3), np.uint8)
+        flat[:] = (90, 140, 200)
+        flat[8:24, 16:40] = (91, 139, 202)
+        flat[40:48, 64:72, 1] += (np.arange(8, dtype=np.uint8) * 9)[None, :]        # one MCU with detail
+        steps = np.empty((h, w, 3), np.uint8)                                       # one colour per MCU, changing from MCU to MCU
+        steps[:, :, 0] = (80 + (np.arange(w) // 8) % 4)[None, :]
+        steps[:, :, 1] = (120 + (np.arange(h) // 8) % 3)[:, None]
+        steps[:, :, 2] = 60
+        steps[16:24, 8:12, 0] += 6                                                   # and one MCU with an edge
+        sources = [steps, flat]
+        files = [po.encode(s, q) for s in sources]
+        want = [torch.from_numpy(po.decode(f, w, h, q).copy()).to(ctx.tdev) for f in files]
+        mcus = ((w + 7) // 8) * (h // 8)
+        assert all(len(f) - 607 < (2.8 if mapper else 2.2) * mcus for f in files), [len(f) for f in files]   # the route's condition
+        kind = np.arange(n) % 2
+        padded = [f + bytes(-len(f) % 64) for f in files]
+        sizes = np.array([len(files[k]) for k in kind], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum([len(padded[k]) for k in kind])[:-1]]).astype(np.uint64)
+        d_jpeg = ctx.to_device(np.frombuffer(b"".join(padded[k] for k in kind), np.uint8))
+        rgb = ctx.decode_batch(d_jpeg, offs, sizes, w, h, lum, chrom).view(n, h, w, 3)
+        wrong = [i for i in range(n) if not torch.equal(rgb[i], want[kind[i]].view(h, w, 3))]
+        assert not wrong, (len(wrong), wrong[:8])
+    finally:
+        po.set_mapper(0)
+        ctx.close()
