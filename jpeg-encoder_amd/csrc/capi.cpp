@@ -1407,7 +1407,8 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     size_t small_files = 0;
     for (size_t i = 0; i < n_images; ++i)
         small_files += (double)(h_sizes[i] - JEA_HEADER_BYTES) < small_limit * (double)mcus;
-    const bool mostly_single_colours = small_files * 10 >= n_images * 9;
+    // (files with per-image Huffman tables are smaller for the same content: their sizes say nothing here)
+    const bool mostly_single_colours = !ctx->optimal_huffman && small_files * 10 >= n_images * 9;
     auto inverse = [&](const DecodeReportRelay& relay) {
         launch_idct_dequant(ctx->stream, (const int16_t*)ctx->coefs.ptr, n_images, width, height, qt, d_rgb,
                             (const uint32_t*)ctx->masks.ptr, ctx->mode, relay, (uint32_t*)ctx->group_flags.ptr,
