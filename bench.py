@@ -563,6 +563,12 @@ def config_c5(job):
     ph = [a / 5 for a in acc]
     stream_bytes = float(sizes.sum())
     px = n * FW * FH
+    # HBM bytes of the inverse transform's kernels from the PMC passes over this configuration (tools/refresh_profiles.sh);
+    # valid for the full 1024-frame call on one GPU
+    pmc5 = pmc_profile("r02_pmc_traffic_c5.json") if (job.world == 1 and n == 1024) else None
+    inverse_traffic = None
+    if pmc5:
+        inverse_traffic = sum(pmc5["kernels"].get(k, {}).get("hbm_bytes_per_launch", 0) for k in ("idct_sparse_kernel", "idct_dequant_kernel"))
     # The inverse transform inside jea_decode_batch reads one 4-byte record per block (12 B per MCU) and the chunks
     # that exist (content dependent, not counted) and writes 3 B/px: that is what it must move at the least.
     inv_bytes = 3.0 * px + 12.0 * n * binding.n_mcu(FW, FH)
@@ -570,7 +576,7 @@ def config_c5(job):
     roofline = {"kernel": "idct_sparse_kernel (+ idct_dequant_kernel for the groups it lists)", "bound": "hbm",
                 "achieved": round(inv_bytes / (ph[3] * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(inv_bytes / (ph[3] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_launch_us": round(ph[3] * 1e3, 1), "algorithmic_bytes_per_launch": int(inv_bytes),
+                "traffic": inverse_traffic, "avg_launch_us": round(ph[3] * 1e3, 1), "algorithmic_bytes_per_launch": int(inv_bytes),
                 "standard_layout_equivalent_GBps": round(std_bytes / (ph[3] * 1e-3) / 1e9, 1),
                 "bound_note": "3 B/px written + 12 B/MCU of block records read; the chunks of blocks with detail come on top. "
                               "Stores and the latency of a workgroup's record -> barrier -> store chain bind it, not arithmetic: "

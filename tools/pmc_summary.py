@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM bytes per launch.
 
-usage: pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> "<workload>" > profiles/xxx.json
+usage: pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> "<workload>" ["<command profiled>"] > profiles/xxx.json
 FETCH_SIZE is doubled (on gfx950 a 128-byte read request is counted as 64 bytes); both counters are in KB."""
 import collections
 import csv
@@ -31,10 +31,10 @@ def per_kernel(directory, counter):
 
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 20 "
-                   "--warmup 2 --ramp-seconds 0 --no-cpu-baseline --streams 1`; FETCH_SIZE doubled for gfx950 (128-byte read requests are "
+    command = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --steps 20 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --streams 1"
+    out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `" + command + "`; FETCH_SIZE doubled for gfx950 (128-byte read requests are "
                    "counted as 64 bytes), WRITE_SIZE taken as is; both in KB; means over the launches of each kernel "
-                   "with its most frequent grid size (the single-image launches)",
+                   "with its most frequent grid size",
            "workload": sys.argv[3], "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else 0.0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates what profiles/ holds for this round, on the GPU box.  Results land in gpurun_out/profiles_new/.
+# Regenerates what profiles/ holds (files named $P_*), on the GPU box.  Results land in gpurun_out/profiles_new/.
 #   bench lines of all configurations, kernel durations (rocprofv3 --kernel-trace --stats) of the headline command with
 #   three contexts and with one, the forward kernel's issue counters and HBM traffic (separate --pmc passes), decode kernels.
 set -o pipefail
@@ -23,6 +23,9 @@ timeout -s KILL 150 rocprofv3 --pmc $SQ --output-format csv -d "$O/pa" -- python
 timeout -s KILL 150 rocprofv3 --pmc $SQ --output-format csv -d "$O/pb" -- python3 "$R/bench.py" $B --pool 64 --marginal-images 64 > "$O/pb.log" 2>&1 || { tail -5 "$O/pb.log"; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pf" -- python3 "$R/bench.py" $B > "$O/pf.log" 2>&1 || { tail -5 "$O/pf.log"; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pw" -- python3 "$R/bench.py" $B > "$O/pw.log" 2>&1 || { tail -5 "$O/pw.log"; exit 1; }
+C5="--config c5 --no-cpu-baseline --steps 2 --warmup 1"
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/qf" -- python3 "$R/bench.py" $C5 > "$O/qf.log" 2>&1 || { tail -5 "$O/qf.log"; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/qw" -- python3 "$R/bench.py" $C5 > "$O/qw.log" 2>&1 || { tail -5 "$O/qw.log"; exit 1; }
 echo counters done
 cd "$R"
 cp "$O"/k3/*/*kernel_stats.csv "$O/${P}_bench_c2_3streams_kernel_stats.csv"
@@ -33,5 +36,6 @@ python3 tools/kernel_trace_summary.py "python3 bench.py $Q" "$O/k3" > "$O/${P}_b
 python3 tools/kernel_trace_summary.py "python3 bench.py --config c5 --no-cpu-baseline" "$O/k5" > "$O/${P}_bench_c5_kernels_by_grid.json"
 python3 tools/k1_issue_summary.py "$O/pa" "$O/pb" "$O/pf" "$O/pw" > "$O/${P}_k1_issue.json" || exit 1
 python3 tools/pmc_summary.py "$O/pf" "$O/pw" "single 3840x2160 q=75 smooth" > "$O/${P}_pmc_traffic.json"
-rm -rf "$O"/k3 "$O"/k1 "$O"/k5 "$O"/pa "$O"/pb "$O"/pf "$O"/pw
+python3 tools/pmc_summary.py "$O/qf" "$O/qw" "decode of 1024 1920x1080 q=50 files in one call" "python3 bench.py $C5" > "$O/${P}_pmc_traffic_c5.json"
+rm -rf "$O"/k3 "$O"/k1 "$O"/k5 "$O"/pa "$O"/pb "$O"/pf "$O"/pw "$O"/qf "$O"/qw
 ls -la "$O"
