@@ -252,7 +252,13 @@ __global__ __launch_bounds__(kFdctThreads, JEA_K1_MIN_WAVES) void fdct_quant_ker
 //     thousand: launches have no long tail, and the loads of the next unit are in flight during the arithmetic.
 // A wave takes `units_per_wave` consecutive units; the launcher picks that number so that the waves of a launch
 // fill the compute units evenly.
-constexpr int kRowWaves = 4;
+#ifndef JEA_ROW_WAVES   // experiments: tools/build_variant.sh <name> -DJEA_ROW_WAVES=<n> -DJEA_ROW_MIN_WAVES=<n>
+#define JEA_ROW_WAVES 4
+#endif
+#ifndef JEA_ROW_MIN_WAVES
+#define JEA_ROW_MIN_WAVES 4
+#endif
+constexpr int kRowWaves = JEA_ROW_WAVES;
 constexpr int kRowThreads = 64 * kRowWaves;
 // LDS layouts, chosen with the banking rules of the LDS in mind (stores: bank = dword mod 32, conflicts among the 32
 // lanes of a half wave, two-way conflicts hidden behind the store's register transfer; 16-byte loads: bank = dword
@@ -312,7 +318,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <bool kPlanar>
-__global__ __launch_bounds__(kRowThreads, 4) void fdct_quant_rows_kernel(
+__global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_rows_kernel(
     const uint8_t* __restrict__ rgb, int width, int height, int blocks_w, uint32_t n_mcu, size_t image_bytes, QuantTables q,
     int16_t* __restrict__ coefs, int32_t* __restrict__ status_to_clear, uint8_t* __restrict__ chunk_masks, ComponentMode mode,
     uint32_t units_per_wave) {
