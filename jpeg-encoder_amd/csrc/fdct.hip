@@ -259,6 +259,10 @@ __global__ __launch_bounds__(kFdctThreads, JEA_K1_MIN_WAVES) void fdct_quant_ker
 #define JEA_ROW_MIN_WAVES 4
 #endif
 constexpr int kRowWaves = JEA_ROW_WAVES;
+#ifndef JEA_ROW_DYN_LDS   // experiments: bytes of unused LDS per workgroup, which limits how many share a compute unit
+#define JEA_ROW_DYN_LDS 0
+#endif
+constexpr int kRowDynLds = JEA_ROW_DYN_LDS;
 constexpr int kRowThreads = 64 * kRowWaves;
 // LDS layouts, chosen with the banking rules of the LDS in mind (stores: bank = dword mod 32, conflicts among the 32
 // lanes of a half wave, two-way conflicts hidden behind the store's register transfer; 16-byte loads: bank = dword
@@ -948,9 +952,14 @@ __global__ __launch_bounds__(kFdctThreads, 6) void idct_sparse_kernel(const int1
         const uint64_t others = ~flat;
         varied[__builtin_amdgcn_mbcnt_hi((uint32_t)(others >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)others, 0u))] = (uint8_t)lane;
     }
+    // One colour: thread t takes MCU t / 3 and the 8-byte piece t % 3 of its 24-byte rows, so that the lanes of
+    // a wave write consecutive bytes.  The rows are worked out here and stored at the very end: the counter that
+    // a wave waits on for a load also counts its stores, so stores issued ahead of the listed MCUs' loads would
+    // have to drain (microseconds when every compute unit is storing) before the transform could start.
+    uint32_t flat_row[2] = {0, 0};
+    uint8_t* flat_to = img;
+    int flat_rows = 0;
     {
-        // One colour: thread t takes MCU t / 3 and the 8-byte piece t % 3 of its 24-byte rows, so that the lanes of
-        // a wave write consecutive bytes.
         const uint32_t fm = (uint32_t)tid / 3u, piece = (uint32_t)tid - 3u * fm;
         if ((flat >> fm) & 1u) {
             const uint32_t mcu = g0 + fm;
@@ -975,12 +984,13 @@ __global__ __launch_bounds__(kFdctThreads, 6) void idct_sparse_kernel(const int1
                 const uint32_t c = (2u * piece + (uint32_t)byte) % 3u;
                 w2[byte >> 2] = insert_byte(c == 0 ? px3[0] : (c == 1 ? px3[1] : px3[2]), byte & 3, w2[byte >> 2]);
             }
-            uint8_t* to = img + ((size_t)by * 8 * width + (size_t)bx * 8) * 3 + 8 * piece;
-            const int rows = height - (int)by * 8 < 8 ? height - (int)by * 8 : 8;
-            for (int r = 0; r < rows; ++r) *reinterpret_cast<uint2*>(to + (size_t)r * width * 3) = make_uint2(w2[0], w2[1]);
+            flat_to = img + ((size_t)by * 8 * width + (size_t)bx * 8) * 3 + 8 * piece;
+            flat_rows = height - (int)by * 8 < 8 ? height - (int)by * 8 : 8;
+            flat_row[0] = w2[0];
+            flat_row[1] = w2[1];
         }
     }
-    if (n_varied == 0) return;
+    if (n_varied != 0) {
     __syncthreads();   // the list is complete
 
     // the listed MCUs, eight per pass: wave = channel, lane = 8 b + s
@@ -1082,6 +1092,9 @@ __global__ __launch_bounds__(kFdctThreads, 6) void idct_sparse_kernel(const int1
         }
         if (first + 8 < n_varied) __syncthreads();   // the next pass overwrites the samples
     }
+    }
+    for (int r = 0; r < flat_rows; ++r)
+        *reinterpret_cast<uint2*>(flat_to + (size_t)r * width * 3) = make_uint2(flat_row[0], flat_row[1]);
 }
 
 __global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, size_t n, uint8_t* __restrict__ ycc) {
@@ -1144,10 +1157,10 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
         const dim3 grid_rows((unsigned)((units + (uint64_t)kRowWaves * best_k - 1) / ((uint64_t)kRowWaves * best_k)),
                              (unsigned)n_images);
         if (planar)
-            fdct_quant_rows_kernel<true><<<grid_rows, kRowThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+            fdct_quant_rows_kernel<true><<<grid_rows, kRowThreads, kRowDynLds, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
                                                                            d_status_to_clear, d_chunk_masks, mode, best_k);
         else
-            fdct_quant_rows_kernel<false><<<grid_rows, kRowThreads, 0, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
+            fdct_quant_rows_kernel<false><<<grid_rows, kRowThreads, kRowDynLds, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
                                                                             d_status_to_clear, d_chunk_masks, mode, best_k);
         return;
     }
