@@ -38,6 +38,11 @@ namespace {
 
 constexpr int kMcusPerGroup = 64;
 constexpr int kFdctThreads = 192;
+// idct_sparse_kernel's occupancy target.  256 smooth 1920x1080 q=50 frames: 8 waves per SIMD (64 registers, spills)
+// 598 us, 7: 475, 6: 391, 5 and 4: 372.
+#ifndef JEA_SPARSE_MIN_WAVES   // experiments: tools/build_variant.sh <name> -DJEA_SPARSE_MIN_WAVES=<n>
+#define JEA_SPARSE_MIN_WAVES 5
+#endif
 constexpr uint32_t kSparseListCapacity = 32768;   // groups idct_sparse_kernel can hand to idct_dequant_kernel
 
 #ifndef JEA_K1_MIN_WAVES
@@ -830,25 +835,32 @@ __global__ __launch_bounds__(kFdctThreads, JEA_IDCT_MIN_WAVES) void idct_dequant
 // The decoder's inverse transform for groups of MCUs that are mostly single colours (smooth pictures at
 // ordinary qualities: all but two or three of a group's 64 MCUs have DC values alone).  In idct_dequant_kernel
 // every lane carries a block, so two blocks with detail cost the wave the whole transform, and its 24 KiB of
-// coefficients in LDS keep the compute units half empty.  Here:
-//   1. thread (channel, MCU) reads its block's record; a block that is its DC value alone is one sample value;
+// coefficients in LDS keep the compute units half empty.  Here a WAVE takes a group of 64 MCUs, lane = MCU:
+//   1. the lane reads its MCU's three records; a block that is its DC value alone is one sample value;
 //   2. MCUs whose three blocks are such values are one colour: converted once and stored as eight rows, from
 //      the records alone (colour_mapping.cpp:69-92, block_grid.cpp:87-99);
-//   3. the other MCUs are listed, and their blocks are transformed eight at a time per wave with the lanes laid
-//      out by block ROW (lane = 8 b + s, as in fdct_quant_rows_kernel): chunks -> LDS -> de-zigzag and dequantise
-//      a row of coefficients (entropy_encoder.cpp:79-92, quantiser.cpp:72-85) -> row pass -> transposition
-//      through LDS -> column pass, clamp, truncation (discrete_cosine_transform.cpp:126-156) -> samples to LDS;
-//      then colour conversion and store of those MCUs' rows.
+//   3. the other MCUs are listed, and their blocks are transformed eight at a time, channel after channel, with
+//      the lanes laid out by block ROW (lane = 8 b + s, as in fdct_quant_rows_kernel): chunks -> LDS -> de-zigzag
+//      and dequantise a row of coefficients (entropy_encoder.cpp:79-92, quantiser.cpp:72-85) -> row pass ->
+//      transposition through LDS -> column pass, clamp, truncation (discrete_cosine_transform.cpp:126-156) ->
+//      samples to LDS; then colour conversion and store of those MCUs' rows.
+// What binds this kernel is the time a group spends waiting for its records and chunks while the whole chip is
+// storing (the stores alone would run at 5.5 TB/s, tools/store_patterns.hip): with a wave per group, and nothing
+// in a group's way that waits for another wave, a compute unit has three times the groups under way that a
+// workgroup of three waves per group had.
 // A group with more than kSparseMaxVaried such MCUs is put on a list and left to idct_dequant_kernel, which is
 // launched behind this kernel with one workgroup per place on the list (a few in the pictures this kernel is
 // for; the launcher sends batches of detailed pictures to idct_dequant_kernel alone).  When the list is full the
 // group is done here after all, in as many passes as it takes.  Needs width % 8 == 0.
 constexpr int kSparseMaxVaried = 16;
 constexpr int kSparseTStride = 72;    // floats per block in the transposition buffer (stores of one x go to 32 different banks)
+constexpr int kSparseWaves = 4;       // groups per workgroup
+static_assert(kRowZWords <= 8 * kSparseTStride, "the chunks share the transposition buffer's space");
 
 // Row-lane inverse transform of eight blocks per wave on the triangle u + v <= D (D = 7: everything).
 // z_block: the block's chunks (zig-zag order) in LDS; qrow: row v of the dequantisation table;
 // out: the eight samples of column x = s, rows y = 0..7, as bytes, in two words.
+// The transposition buffer may lie over the chunks: they are read before it is written.
 template <int D>
 __device__ __forceinline__ void idct_rowlane(const uint8_t* z_block, const uint32_t (&z_off)[8], const float* qrow,
                                              float* t_write, const float* t_read, uint32_t (&out)[2]) {
@@ -861,6 +873,7 @@ __device__ __forceinline__ void idct_rowlane(const uint8_t* z_block, const uint3
         for (int u = 0; u < kTerms; ++u)
             deq[u] = (float)(int)*reinterpret_cast<const int16_t*>(z_block + z_off[u]) * qv[u];
     }
+    wave_lds_fence();
     // row pass :126-135: tmp[x][v] = sum_u (s(u)C[u][x]) * src[u + 8v]; rows beyond the triangle hold zeros
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
@@ -888,213 +901,260 @@ __device__ __forceinline__ void idct_rowlane(const uint8_t* z_block, const uint3
     }
 }
 
-__global__ __launch_bounds__(kFdctThreads, 6) void idct_sparse_kernel(const int16_t* __restrict__ coefs,
-                                                                       const uint32_t* __restrict__ records, int width,
-                                                                       int height, int blocks_w, uint32_t n_mcu,
-                                                                       size_t image_bytes, QuantTables q,
-                                                                       uint8_t* __restrict__ rgb, ComponentMode mode,
-                                                                       DecodeReportRelay relay,
-                                                                       uint32_t* __restrict__ group_list) {
+__global__ __launch_bounds__(64 * kSparseWaves, JEA_SPARSE_MIN_WAVES) void idct_sparse_kernel(
+    const int16_t* __restrict__ coefs, const uint32_t* __restrict__ records, int width, int height, int blocks_w,
+    uint32_t n_mcu, size_t image_bytes, QuantTables q, uint8_t* __restrict__ rgb, ComponentMode mode,
+    DecodeReportRelay relay, uint32_t* __restrict__ group_list, uint32_t groups_per_image) {
     // the decoder's outcome, known since the kernels before this one ended, goes to the host on the side
     if (relay.report != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         relay.report->unsettled = *relay.unsettled;
         relay.report->status = *relay.status;
     }
-    __shared__ uint8_t lds_dc[3 * kMcusPerGroup];    // sample value of a block that is its DC value alone
-    __shared__ uint32_t lds_rec[3 * kMcusPerGroup];  // the group's records, [channel][MCU]
-    __shared__ __align__(16) uint4 lds_first[3 * kMcusPerGroup];   // first chunk of the blocks that have one stored
-    __shared__ uint64_t dc_alone_of[3];
-    __shared__ uint8_t varied[kMcusPerGroup];
     __shared__ __align__(16) float lds_qt[128];      // dequantisation tables, natural order: luminance | chrominance
-    __shared__ __align__(16) float lds_t[3][8 * kSparseTStride];
-    __shared__ __align__(16) uint32_t lds_z[3][kRowZWords];
-    __shared__ __align__(16) uint8_t lds_px[3 * 8 * 64];   // samples of the eight MCUs of a pass, [channel][b][y][x]
+    __shared__ __align__(16) float lds_tz[kSparseWaves][8 * kSparseTStride];   // a wave's chunks, then its transposition buffer
+    // samples of the eight MCUs of a pass, [channel][b][y][x], which their pixels then replace, [b][y][24 bytes]; two passes' worth
+    __shared__ __align__(16) uint8_t lds_px[kSparseWaves][2][3 * 8 * 64];
+    __shared__ uint8_t lds_varied[kSparseWaves][kMcusPerGroup];
 
     const int tid = threadIdx.x;
-    const uint32_t g0 = blockIdx.x * kMcusPerGroup;
-    uint8_t* img = rgb + (size_t)blockIdx.y * image_bytes;
-    const uint32_t mcus_here = (n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup;
-    const int channel = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = (uint32_t)tid & 63u;
-    const uint32_t* rec_image = records + (size_t)blockIdx.y * n_mcu * 3;
+    const uint32_t group = blockIdx.x * (uint32_t)kSparseWaves + (uint32_t)wave;
+    const bool has_group = group < groups_per_image;   // per wave
+    const uint32_t g0 = group * kMcusPerGroup;
+    const uint32_t mcus_here = !has_group ? 0u : ((n_mcu - g0 < (uint32_t)kMcusPerGroup) ? (n_mcu - g0) : (uint32_t)kMcusPerGroup);
+    const bool valid = lane < mcus_here;
+    const uint32_t mcu_own = g0 + lane;
+    uint8_t* const img = rgb + (size_t)blockIdx.y * image_bytes;
 
-    {
-        const bool valid = lane < mcus_here;
-        const uint32_t rec = valid ? rec_image[(g0 + lane) * 3 + channel] : 0u;
-        if (tid < 128) lds_qt[tid] = reinterpret_cast<const float*>(&q)[tid];
-        const float q0 = mode.is_lum(channel) ? q.lum[0] : q.chr[0];
-        // DC alone: every sample is s(0)C[0][y] * (s(0)C[0][x] * deq[0]) with C[0][.] = 1, clamped and truncated (:144-154)
-        const float dc_only = inv_c(0, 0) * (inv_c(0, 0) * ((float)(int)(int16_t)(rec & 0xffffu) * q0));
-        lds_dc[channel * kMcusPerGroup + lane] = (uint8_t)((int)__builtin_amdgcn_fmed3f(dc_only, -128.0f, 127.0f) + 128);
-        const uint64_t alone = __ballot(valid && ((rec >> 16) & 0xffu) == 0);
-        if (lane == 0) dc_alone_of[channel] = alone;
-        // what the transform of the listed MCUs will want is asked for now, so that it is there by then: the
-        // record goes to LDS, and so does the first chunk of a block that has one (few lanes; later chunks are rare
-        // in the pictures this kernel is for and are fetched when they are needed)
-        lds_rec[channel * kMcusPerGroup + lane] = rec;
-        if ((rec >> 16) & 1u)
-            lds_first[channel * kMcusPerGroup + lane] =
-                (reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu)[g0 + lane];
+    uint32_t rec[3] = {0u, 0u, 0u};
+    if (valid) {
+        const uint32_t* r = records + ((size_t)blockIdx.y * n_mcu + mcu_own) * 3;
+        rec[0] = r[0]; rec[1] = r[1]; rec[2] = r[2];
     }
-    __syncthreads();
-    const uint64_t flat = dc_alone_of[0] & dc_alone_of[1] & dc_alone_of[2];
-    const uint32_t n_varied = mcus_here - (uint32_t)__popcll(flat);
+    if (tid < 128) lds_qt[tid] = reinterpret_cast<const float*>(&q)[tid];
+    __syncthreads();   // the only workgroup barrier
+    if (!has_group) return;
+
+    const bool lane_flat = valid && (((rec[0] | rec[1] | rec[2]) >> 16) & 0xffu) == 0;
+    const uint64_t flat = __ballot(lane_flat), others = __ballot(valid && !lane_flat);
+    const uint32_t n_varied = (uint32_t)__popcll(others);
     if (n_varied > (uint32_t)kSparseMaxVaried) {   // for idct_dequant_kernel, if the list has room
-        __shared__ uint32_t place;
-        if (tid == 0) {
+        uint32_t place = 0;
+        if (lane == 0) {
             place = atomicAdd(group_list, 1u);
-            if (place < kSparseListCapacity) group_list[1 + place] = blockIdx.y * gridDim.x + blockIdx.x;
+            if (place < kSparseListCapacity) group_list[1 + place] = blockIdx.y * groups_per_image + group;
         }
-        __syncthreads();
+        place = (uint32_t)__builtin_amdgcn_readfirstlane((int)place);
         if (place < kSparseListCapacity) return;
     }
-    if (channel == 0 && lane < mcus_here && !((flat >> lane) & 1u)) {
-        const uint64_t others = ~flat;
-        varied[__builtin_amdgcn_mbcnt_hi((uint32_t)(others >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)others, 0u))] = (uint8_t)lane;
-    }
-    // One colour: thread t takes MCU t / 3 and the 8-byte piece t % 3 of its 24-byte rows, so that the lanes of
-    // a wave write consecutive bytes.  The rows are worked out here and stored at the very end: the counter that
-    // a wave waits on for a load also counts its stores, so stores issued ahead of the listed MCUs' loads would
-    // have to drain (microseconds when every compute unit is storing) before the transform could start.
-    uint32_t flat_row[2] = {0, 0};
-    uint8_t* flat_to = img;
-    int flat_rows = 0;
-    {
-        const uint32_t fm = (uint32_t)tid / 3u, piece = (uint32_t)tid - 3u * fm;
-        if ((flat >> fm) & 1u) {
-            const uint32_t mcu = g0 + fm;
-            const uint32_t by = mcu / (uint32_t)blocks_w, bx = mcu - by * (uint32_t)blocks_w;
-            const int c0 = lds_dc[fm], c1 = lds_dc[kMcusPerGroup + fm], c2 = lds_dc[2 * kMcusPerGroup + fm];
-            float px3[3];
-            if (mode.passthrough) {
-                px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
-            } else {
-                bool tie;
-                colour_inverse_fast_unclamped((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);
-                if (tie) {   // the literal formula
-                    uint8_t rr, gg, bb;
-                    colour_inverse(c0, c1, c2, rr, gg, bb);
-                    px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
-                }
-            }
-            // eight pixels are the 24 bytes RGBR GBRG BRGB RGBR GBRG BRGB; piece p starts at byte 8 p, with colour 2 p mod 3
-            uint32_t w2[2] = {0, 0};
+    // Chunk s of channel c of MCU m of this picture is chunk_image[(3 s + c) n_mcu + m].  What the transform of a
+    // listed MCU will want first is asked for now: the first chunk of each of its blocks that has one stored (a
+    // block without carries its DC value in the record).
+    const uint4* const chunk_image = reinterpret_cast<const uint4*>(coefs) + (size_t)blockIdx.y * 24 * n_mcu;
+    uint4 fc[3];
 #pragma unroll
-            for (int byte = 0; byte < 8; ++byte) {
-                const uint32_t c = (2u * piece + (uint32_t)byte) % 3u;
-                w2[byte >> 2] = insert_byte(c == 0 ? px3[0] : (c == 1 ? px3[1] : px3[2]), byte & 3, w2[byte >> 2]);
-            }
-            flat_to = img + ((size_t)by * 8 * width + (size_t)bx * 8) * 3 + 8 * piece;
-            flat_rows = height - (int)by * 8 < 8 ? height - (int)by * 8 : 8;
-            flat_row[0] = w2[0];
-            flat_row[1] = w2[1];
-        }
+    for (int c = 0; c < 3; ++c) {
+        fc[c] = make_uint4(rec[c] & 0xffffu, 0u, 0u, 0u);
+        if ((rec[c] >> 16) & 1u) fc[c] = chunk_image[(size_t)c * n_mcu + mcu_own];
     }
-    if (n_varied != 0) {
-    __syncthreads();   // the list is complete
 
-    // the listed MCUs, eight per pass: wave = channel, lane = 8 b + s
-    const uint32_t b = lane >> 3, s = lane & 7u;
-    const uint32_t b_lo = b & 1u, b_hi = (b >> 1) & 1u;
-    uint8_t* const z_block = reinterpret_cast<uint8_t*>(lds_z[channel] + 36u * (b_lo ^ b_hi) + 80u * b_hi + 148u * (b >> 2));
-    float* const t_write = lds_t[channel] + b * kSparseTStride + s;        // + 8 x: value (x, row v = s)
-    const float* const t_read = lds_t[channel] + b * kSparseTStride + 8 * s;   // + v: value (x = s, row v)
-    const float* const qrow = lds_qt + (mode.is_lum(channel) ? 0 : 64) + 8 * s;
-    uint32_t z_off[8];   // byte offset of coefficient (v = s, u) in the block's zig-zag order
+    // One colour.  DC alone: every sample is s(0)C[0][y] * (s(0)C[0][x] * deq[0]) with C[0][.] = 1, clamped and
+    // truncated (:144-154); the lane converts its MCU's colour (used if the MCU is one) and notes where the MCU lies.
+    uint32_t own_colour = 0, own_place;
     {
-        const uint32_t pick_byte_s = 0x0c0c0c00u | s;
+        float dcs[3];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint64_t col = kZigzagColDoubled[u];
-            z_off[u] = __builtin_amdgcn_perm((uint32_t)(col >> 32), (uint32_t)col, pick_byte_s);
+        for (int c = 0; c < 3; ++c) {
+            const float q0 = mode.is_lum(c) ? q.lum[0] : q.chr[0];
+            const float dc_only = inv_c(0, 0) * (inv_c(0, 0) * ((float)(int)(int16_t)(rec[c] & 0xffffu) * q0));
+            dcs[c] = (float)((int)__builtin_amdgcn_fmed3f(dc_only, -128.0f, 127.0f) + 128);
         }
+        float px3[3];
+        if (mode.passthrough) {
+            px3[0] = dcs[0]; px3[1] = dcs[1]; px3[2] = dcs[2];
+        } else {
+            bool tie;
+            colour_inverse_fast_unclamped(dcs[0], dcs[1], dcs[2], px3[0], px3[1], px3[2], tie);
+            if (tie) {   // the literal formula
+                uint8_t rr, gg, bb;
+                colour_inverse((int)dcs[0], (int)dcs[1], (int)dcs[2], rr, gg, bb);
+                px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
+            }
+        }
+        own_colour = insert_byte(px3[0], 0, insert_byte(px3[1], 1, insert_byte(px3[2], 2, 0u)));
+        const uint32_t mcu_in = mcu_own < n_mcu ? mcu_own : n_mcu - 1u;
+        const uint32_t by = mcu_in / (uint32_t)blocks_w, bx = mcu_in - by * (uint32_t)blocks_w;
+        own_place = by << 16 | bx;   // both below 8192
     }
-    const uint4* plane_image = reinterpret_cast<const uint4*>(coefs) + ((size_t)blockIdx.y * 24 + channel) * n_mcu;
-    for (uint32_t first = 0; first < n_varied; first += 8) {
-        const uint32_t n_here = n_varied - first < 8u ? n_varied - first : 8u;
-        const bool live = b < n_here;
-        const uint32_t mm = varied[live ? first + b : first];
-        const uint32_t mcu = g0 + mm;
-        const uint32_t rec = lds_rec[channel * kMcusPerGroup + mm];
-        const uint32_t mask = live ? (rec >> 16) & 0xffu : 0u;
-        const bool have = (mask >> s) & 1u;
-        uint4 chunk = make_uint4(0, 0, 0, 0);
-        if (have) {
-            if (s == 0) chunk = lds_first[channel * kMcusPerGroup + mm];
-            else chunk = plane_image[(size_t)s * 3 * n_mcu + mcu];
-        }
-        if (s == 0 && !have) chunk.x = rec & 0xffffu;   // no stored first chunk: the DC value from the record
-        *reinterpret_cast<uint4*>(z_block + 16 * s) = chunk;
-        // how far along the zig-zag do the coefficients of the wave's eight blocks reach?  (chunk 0: positions 0-7
-        // = diagonals u + v <= 3, words 0-1 | 2-3 | 4-5 | 6-7 on diagonals 0,1 | 1,2 | 2,2 | 3,3; chunk 1: <= 5)
-        int diag;
-        if (__ballot(have && s >= 2) != 0) diag = 7;
-        else if (__ballot(have && s == 1) != 0) diag = 5;
-        else if (__ballot(s == 0 && chunk.w != 0) != 0) diag = 3;
-        else if (__ballot(s == 0 && (chunk.y | chunk.z) != 0) != 0) diag = 2;
-        else diag = 1;
-        wave_lds_fence();
-        uint32_t col8[2];
-        switch (diag) {
-            case 1: idct_rowlane<1>(z_block, z_off, qrow, t_write, t_read, col8); break;
-            case 2: idct_rowlane<2>(z_block, z_off, qrow, t_write, t_read, col8); break;
-            case 3: idct_rowlane<3>(z_block, z_off, qrow, t_write, t_read, col8); break;
-            case 5: idct_rowlane<5>(z_block, z_off, qrow, t_write, t_read, col8); break;
-            default: idct_rowlane<7>(z_block, z_off, qrow, t_write, t_read, col8); break;
-        }
-        // column x = s of block b: bytes y = 0..7 go to [channel][b][y][x]
+
+    // place of a listed MCU on the list (for the others: how many listed MCUs come before them)
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(others >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)others, 0u));
+    if (n_varied != 0) {
+        const bool listed = (others >> lane) & 1u;
+        if (listed) lds_varied[wave][rank] = (uint8_t)lane;
+        // the listed MCUs, eight per pass, channel after channel: lane = 8 b + s
+        const uint32_t b = lane >> 3, s = lane & 7u;
+        float* const tz = lds_tz[wave];
+        uint8_t* const z_block = reinterpret_cast<uint8_t*>(tz + 36u * ((b & 1u) ^ ((b >> 1) & 1u)) + 80u * ((b >> 1) & 1u) + 148u * (b >> 2));
+        float* const t_write = tz + b * kSparseTStride + s;        // + 8 x: value (x, row v = s)
+        const float* const t_read = tz + b * kSparseTStride + 8 * s;   // + v: value (x = s, row v)
+        uint32_t z_off[8];   // byte offset of coefficient (v = s, u) in the block's zig-zag order
         {
-            uint8_t* to = lds_px + ((uint32_t)channel * 8u + b) * 64u + s;
+            const uint32_t pick_byte_s = 0x0c0c0c00u | s;
 #pragma unroll
-            for (int y = 0; y < 8; ++y) to[8 * y] = (uint8_t)(col8[y >> 2] >> (8 * (y & 3)));
+            for (int u = 0; u < 8; ++u) {
+                const uint64_t col = kZigzagColDoubled[u];
+                z_off[u] = __builtin_amdgcn_perm((uint32_t)(col >> 32), (uint32_t)col, pick_byte_s);
+            }
         }
-        __syncthreads();
-        // colour conversion and store: work item = (row r, MCU bi of the pass) = 8 pixels = 24 contiguous bytes
-        if ((uint32_t)tid < 8u * n_here) {
-            const uint32_t r = (uint32_t)tid / n_here, bi = (uint32_t)tid - r * n_here;
-            const uint32_t mcu2 = g0 + varied[first + bi];
-            const uint32_t by = mcu2 / (uint32_t)blocks_w, bx = mcu2 - by * (uint32_t)blocks_w;
-            const int y = (int)by * 8 + (int)r;
-            if (y < height) {
-                const uint2 y8 = *reinterpret_cast<const uint2*>(lds_px + (0 * 8 + bi) * 64 + r * 8);
-                const uint2 b8 = *reinterpret_cast<const uint2*>(lds_px + (1 * 8 + bi) * 64 + r * 8);
-                const uint2 r8 = *reinterpret_cast<const uint2*>(lds_px + (2 * 8 + bi) * 64 + r * 8);
-                const uint32_t yy[2] = {y8.x, y8.y}, cbb[2] = {b8.x, b8.y}, crr[2] = {r8.x, r8.y};
-                uint32_t out[6] = {0, 0, 0, 0, 0, 0};
+        wave_lds_fence();
+        // The pixels of the first 16 listed MCUs (all of them, unless the group was too detailed for this kernel and
+        // the list was full) stay in LDS and leave with the single colours' rows; passes beyond those store their
+        // own, and run first, while the LDS space is free.
+        for (int pass = (int)((n_varied - 1u) >> 3); pass >= 0; --pass) {
+            const uint32_t first = 8u * (uint32_t)pass;
+            uint8_t* const px = lds_px[wave][pass == 1 ? 1 : 0];
+            const uint32_t n_here = n_varied - first < 8u ? n_varied - first : 8u;
+            const bool live = b < n_here;
+            const uint32_t mm = lds_varied[wave][live ? first + b : first];
+            // a listed lane whose MCU is in this pass puts its first chunks where block (rank - first) has its chunk 0
+            const uint32_t slot = rank - first;
+            const bool in_pass = listed && slot < 8u;
+            uint8_t* const z_mine = reinterpret_cast<uint8_t*>(tz + 36u * ((slot & 1u) ^ ((slot >> 1) & 1u)) + 80u * ((slot >> 1) & 1u) + 148u * ((slot >> 2) & 1u));
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t rec_c = c == 0 ? rec[0] : (c == 1 ? rec[1] : rec[2]);
+                uint4 fc_c;
+                fc_c.x = c == 0 ? fc[0].x : (c == 1 ? fc[1].x : fc[2].x);
+                fc_c.y = c == 0 ? fc[0].y : (c == 1 ? fc[1].y : fc[2].y);
+                fc_c.z = c == 0 ? fc[0].z : (c == 1 ? fc[1].z : fc[2].z);
+                fc_c.w = c == 0 ? fc[0].w : (c == 1 ? fc[1].w : fc[2].w);
+                const uint32_t rec_mm = (uint32_t)__shfl((int)rec_c, (int)mm);
+                const uint32_t mask = live ? (rec_mm >> 16) & 0xffu : 0u;
+                const bool have = (mask >> s) & 1u;
+                if (in_pass) *reinterpret_cast<uint4*>(z_mine) = fc_c;
+                if (s == 0) {
+                    if (!live) *reinterpret_cast<uint4*>(z_block) = make_uint4(0, 0, 0, 0);
+                } else {
+                    uint4 chunk = make_uint4(0, 0, 0, 0);
+                    if (have) chunk = chunk_image[((size_t)s * 3 + (size_t)c) * n_mcu + g0 + mm];
+                    *reinterpret_cast<uint4*>(z_block + 16 * s) = chunk;
+                }
+                // how far along the zig-zag do the coefficients of the wave's eight blocks reach?  (chunk 0: positions 0-7
+                // = diagonals u + v <= 3, words 0-1 | 2-3 | 4-5 | 6-7 on diagonals 0,1 | 1,2 | 2,2 | 3,3; chunk 1: <= 5)
+                int diag;
+                if (__ballot(have && s >= 2) != 0) diag = 7;
+                else if (__ballot(have && s == 1) != 0) diag = 5;
+                else if (__ballot(in_pass && fc_c.w != 0) != 0) diag = 3;
+                else if (__ballot(in_pass && (fc_c.y | fc_c.z) != 0) != 0) diag = 2;
+                else diag = 1;
+                wave_lds_fence();
+                const float* const qrow = lds_qt + (mode.is_lum(c) ? 0 : 64) + 8 * s;
+                uint32_t col8[2];
+                switch (diag) {
+                    case 1: idct_rowlane<1>(z_block, z_off, qrow, t_write, t_read, col8); break;
+                    case 2: idct_rowlane<2>(z_block, z_off, qrow, t_write, t_read, col8); break;
+                    case 3: idct_rowlane<3>(z_block, z_off, qrow, t_write, t_read, col8); break;
+                    case 5: idct_rowlane<5>(z_block, z_off, qrow, t_write, t_read, col8); break;
+                    default: idct_rowlane<7>(z_block, z_off, qrow, t_write, t_read, col8); break;
+                }
+                // column x = s of block b: bytes y = 0..7 go to [channel][b][y][x]
+                uint8_t* to = px + ((uint32_t)c * 8u + b) * 64u + s;
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const int sh = 8 * (p & 3);
-                    const int c0 = (int)((yy[p >> 2] >> sh) & 0xffu), c1 = (int)((cbb[p >> 2] >> sh) & 0xffu),
-                              c2 = (int)((crr[p >> 2] >> sh) & 0xffu);
-                    float px3[3];
-                    if (mode.passthrough) {   // colour_mapping.cpp:28-37
-                        px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
-                    } else {
-                        bool tie;
-                        colour_inverse_fast_unclamped((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);   // insert_byte clamps
-                        if (tie) {   // the literal formula
-                            uint8_t rr, gg, bb;
-                            colour_inverse(c0, c1, c2, rr, gg, bb);
-                            px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
+                for (int y = 0; y < 8; ++y) to[8 * y] = (uint8_t)(col8[y >> 2] >> (8 * (y & 3)));
+            }
+            wave_lds_fence();
+            // colour conversion: lane = (row r, MCU bi of the pass) = 8 pixels = 24 bytes
+            {
+                const uint32_t r = lane >> 3, bi = lane & 7u;
+                const bool mine = bi < n_here;
+                uint32_t out[6] = {0, 0, 0, 0, 0, 0};
+                if (mine) {
+                    const uint2 y8 = *reinterpret_cast<const uint2*>(px + (0 * 8 + bi) * 64 + r * 8);
+                    const uint2 b8 = *reinterpret_cast<const uint2*>(px + (1 * 8 + bi) * 64 + r * 8);
+                    const uint2 r8 = *reinterpret_cast<const uint2*>(px + (2 * 8 + bi) * 64 + r * 8);
+                    const uint32_t yy[2] = {y8.x, y8.y}, cbb[2] = {b8.x, b8.y}, crr[2] = {r8.x, r8.y};
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const int sh = 8 * (p & 3);
+                        const int c0 = (int)((yy[p >> 2] >> sh) & 0xffu), c1 = (int)((cbb[p >> 2] >> sh) & 0xffu),
+                                  c2 = (int)((crr[p >> 2] >> sh) & 0xffu);
+                        float px3[3];
+                        if (mode.passthrough) {   // colour_mapping.cpp:28-37
+                            px3[0] = (float)c0; px3[1] = (float)c1; px3[2] = (float)c2;
+                        } else {
+                            bool tie;
+                            colour_inverse_fast_unclamped((float)c0, (float)c1, (float)c2, px3[0], px3[1], px3[2], tie);   // insert_byte clamps
+                            if (tie) {   // the literal formula
+                                uint8_t rr, gg, bb;
+                                colour_inverse(c0, c1, c2, rr, gg, bb);
+                                px3[0] = (float)rr; px3[1] = (float)gg; px3[2] = (float)bb;
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int byte = 3 * p + c;
+                            out[byte >> 2] = insert_byte(px3[c], byte & 3, out[byte >> 2]);
                         }
                     }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int byte = 3 * p + c;
-                        out[byte >> 2] = insert_byte(px3[c], byte & 3, out[byte >> 2]);
+                }
+                wave_lds_fence();   // every lane has its samples: the pixels may take their place
+                if (mine) {
+                    if (pass < 2) {
+                        uint2* dst = reinterpret_cast<uint2*>(px + (bi * 8u + r) * 24u);
+                        dst[0] = make_uint2(out[0], out[1]);
+                        dst[1] = make_uint2(out[2], out[3]);
+                        dst[2] = make_uint2(out[4], out[5]);
+                    } else {
+                        const uint32_t mcu2 = g0 + lds_varied[wave][first + bi];
+                        const uint32_t by = mcu2 / (uint32_t)blocks_w, bx = mcu2 - by * (uint32_t)blocks_w;
+                        const int y = (int)by * 8 + (int)r;
+                        if (y < height) {
+                            uint2* dst = reinterpret_cast<uint2*>(img + ((size_t)y * width + (size_t)bx * 8) * 3);
+                            dst[0] = make_uint2(out[0], out[1]);
+                            dst[1] = make_uint2(out[2], out[3]);
+                            dst[2] = make_uint2(out[4], out[5]);
+                        }
                     }
                 }
-                uint2* dst = reinterpret_cast<uint2*>(img + ((size_t)y * width + (size_t)bx * 8) * 3);
-                dst[0] = make_uint2(out[0], out[1]);
-                dst[1] = make_uint2(out[2], out[3]);
-                dst[2] = make_uint2(out[4], out[5]);
             }
+            wave_lds_fence();   // the next pass may use the same space
         }
-        if (first + 8 < n_varied) __syncthreads();   // the next pass overwrites the samples
     }
+
+    // The group's rows, last: the counter a wave waits on for a load also counts its stores, so stores issued ahead
+    // of the listed MCUs' loads would have to drain first.  A row of the group is 64 x 24 bytes; lane l writes the
+    // 8-byte pieces l, l + 64, l + 128 of it (piece p: MCU p / 3, bytes 8 (p % 3) ...), so that a store instruction
+    // of the wave covers 512 consecutive bytes, single colours and listed MCUs alike (rows with holes, filled
+    // by other stores later, cost a tenth of the store rate: tools/store_patterns.hip).  Eight pixels of one colour
+    // are the 24 bytes RGBR GBRG BRGB RGBR GBRG BRGB: piece 0 = RGBR GBRG, piece 1 = BRGB RGBR, piece 2 = GBRG BRGB.
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+        const uint32_t p = lane + 64u * k, fm = p / 3u, piece = p - 3u * fm;
+        const uint32_t colour = (uint32_t)__shfl((int)own_colour, (int)fm), place = (uint32_t)__shfl((int)own_place, (int)fm);
+        const uint32_t rank_fm = (uint32_t)__shfl((int)rank, (int)fm);
+        const bool is_flat = (flat >> fm) & 1u, is_kept = ((others >> fm) & 1u) && rank_fm < 16u;
+        if (is_flat || is_kept) {
+            const uint32_t by = place >> 16, bx = place & 0xffffu;
+            constexpr uint32_t kRgbr = 0x00020100u, kGbrg = 0x01000201u, kBrgb = 0x02010002u;
+            const uint32_t w0 = __builtin_amdgcn_perm(colour, colour, piece == 0 ? kRgbr : (piece == 1 ? kBrgb : kGbrg));
+            const uint32_t w1 = __builtin_amdgcn_perm(colour, colour, piece == 0 ? kGbrg : (piece == 1 ? kRgbr : kBrgb));
+            uint2 row[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) row[r] = make_uint2(w0, w1);
+            if (is_kept) {
+                const uint8_t* from = lds_px[wave][rank_fm >> 3] + (rank_fm & 7u) * 192u + 8u * piece;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) row[r] = *reinterpret_cast<const uint2*>(from + 24 * r);
+            }
+            uint8_t* to = img + ((size_t)by * 8 * width + (size_t)bx * 8) * 3 + 8 * piece;
+            const int rows = height - (int)by * 8 < 8 ? height - (int)by * 8 : 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r < rows) *reinterpret_cast<uint2*>(to + (size_t)r * width * 3) = row[r];
+        }
     }
-    for (int r = 0; r < flat_rows; ++r)
-        *reinterpret_cast<uint2*>(flat_to + (size_t)r * width * 3) = make_uint2(flat_row[0], flat_row[1]);
 }
 
 __global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, size_t n, uint8_t* __restrict__ ycc) {
@@ -1191,8 +1251,9 @@ void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images,
     if (d_records != nullptr && d_group_list != nullptr && mostly_single_colours && width % 8 == 0 &&
         total_groups >= 8192 && total_groups < (1ull << 32)) {
         (void)hipMemsetAsync(d_group_list, 0, sizeof(uint32_t), s);
-        idct_sparse_kernel<<<grid, kFdctThreads, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu, image_bytes, q,
-                                                         d_rgb, mode, relay, d_group_list);
+        const dim3 grid_sparse((grid.x + kSparseWaves - 1) / kSparseWaves, (unsigned)n_images);
+        idct_sparse_kernel<<<grid_sparse, 64 * kSparseWaves, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu, image_bytes, q,
+                                                                     d_rgb, mode, relay, d_group_list, grid.x);
         const dim3 grid_listed((unsigned)(total_groups < kSparseListCapacity ? total_groups : kSparseListCapacity), 1);
         idct_dequant_kernel<true><<<grid_listed, kFdctThreads, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu,
                                                                        image_bytes, q, d_rgb, mode, DecodeReportRelay{},
