@@ -1403,7 +1403,11 @@ int jea_decode_batch(jea_ctx* ctx, const uint8_t* d_jpeg, const uint64_t* h_offs
     // little (a few noise frames among smooth ones lift it past 2.7): nine files in ten must be under 2.2 B/MCU.
     // (With the pass-through mapper all three components use the luminance codes, whose end-of-block code is two
     // bits longer than the chrominance one: 2.25 to about 2.8 bytes for an MCU of one colour.)
+#ifdef JEA_SMALL_LIMIT   // experiments
+    const double small_limit = JEA_SMALL_LIMIT;
+#else
     const double small_limit = ctx->mode.passthrough ? 2.8 : 2.2;
+#endif
     size_t small_files = 0;
     for (size_t i = 0; i < n_images; ++i)
         small_files += (double)(h_sizes[i] - JEA_HEADER_BYTES) < small_limit * (double)mcus;

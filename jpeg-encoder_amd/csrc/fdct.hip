@@ -852,7 +852,11 @@ __global__ __launch_bounds__(kFdctThreads, JEA_IDCT_MIN_WAVES) void idct_dequant
 // launched behind this kernel with one workgroup per place on the list (a few in the pictures this kernel is
 // for; the launcher sends batches of detailed pictures to idct_dequant_kernel alone).  When the list is full the
 // group is done here after all, in as many passes as it takes.  Needs width % 8 == 0.
-constexpr int kSparseMaxVaried = 16;
+#ifndef JEA_SPARSE_KEPT_PASSES   // experiments: tools/build_variant.sh <name> -DJEA_SPARSE_KEPT_PASSES=<n>
+#define JEA_SPARSE_KEPT_PASSES 2
+#endif
+constexpr int kSparseKeptPasses = JEA_SPARSE_KEPT_PASSES;   // passes (of eight listed MCUs) whose pixels have a place in LDS
+constexpr int kSparseMaxVaried = 8 * kSparseKeptPasses;
 constexpr int kSparseTStride = 72;    // floats per block in the transposition buffer (stores of one x go to 32 different banks)
 constexpr int kSparseWaves = 4;       // groups per workgroup
 static_assert(kRowZWords <= 8 * kSparseTStride, "the chunks share the transposition buffer's space");
@@ -912,8 +916,8 @@ __global__ __launch_bounds__(64 * kSparseWaves, JEA_SPARSE_MIN_WAVES) void idct_
     }
     __shared__ __align__(16) float lds_qt[128];      // dequantisation tables, natural order: luminance | chrominance
     __shared__ __align__(16) float lds_tz[kSparseWaves][8 * kSparseTStride];   // a wave's chunks, then its transposition buffer
-    // samples of the eight MCUs of a pass, [channel][b][y][x], which their pixels then replace, [b][y][24 bytes]; two passes' worth
-    __shared__ __align__(16) uint8_t lds_px[kSparseWaves][2][3 * 8 * 64];
+    // samples of the eight MCUs of a pass, [channel][b][y][x], which their pixels then replace, [b][y][24 bytes]; kSparseKeptPasses passes' worth
+    __shared__ __align__(16) uint8_t lds_px[kSparseWaves][kSparseKeptPasses][3 * 8 * 64];
     __shared__ uint8_t lds_varied[kSparseWaves][kMcusPerGroup];
 
     const int tid = threadIdx.x;
@@ -1009,12 +1013,12 @@ __global__ __launch_bounds__(64 * kSparseWaves, JEA_SPARSE_MIN_WAVES) void idct_
             }
         }
         wave_lds_fence();
-        // The pixels of the first 16 listed MCUs (all of them, unless the group was too detailed for this kernel and
+        // The pixels of the first kSparseMaxVaried listed MCUs (all of them, unless the group was too detailed for this kernel and
         // the list was full) stay in LDS and leave with the single colours' rows; passes beyond those store their
         // own, and run first, while the LDS space is free.
         for (int pass = (int)((n_varied - 1u) >> 3); pass >= 0; --pass) {
             const uint32_t first = 8u * (uint32_t)pass;
-            uint8_t* const px = lds_px[wave][pass == 1 ? 1 : 0];
+            uint8_t* const px = lds_px[wave][pass < kSparseKeptPasses ? pass : 0];
             const uint32_t n_here = n_varied - first < 8u ? n_varied - first : 8u;
             const bool live = b < n_here;
             const uint32_t mm = lds_varied[wave][live ? first + b : first];
@@ -1101,7 +1105,7 @@ __global__ __launch_bounds__(64 * kSparseWaves, JEA_SPARSE_MIN_WAVES) void idct_
                 }
                 wave_lds_fence();   // every lane has its samples: the pixels may take their place
                 if (mine) {
-                    if (pass < 2) {
+                    if (pass < kSparseKeptPasses) {
                         uint2* dst = reinterpret_cast<uint2*>(px + (bi * 8u + r) * 24u);
                         dst[0] = make_uint2(out[0], out[1]);
                         dst[1] = make_uint2(out[2], out[3]);
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(64 * kSparseWaves, JEA_SPARSE_MIN_WAVES) void idct_
         const uint32_t p = lane + 64u * k, fm = p / 3u, piece = p - 3u * fm;
         const uint32_t colour = (uint32_t)__shfl((int)own_colour, (int)fm), place = (uint32_t)__shfl((int)own_place, (int)fm);
         const uint32_t rank_fm = (uint32_t)__shfl((int)rank, (int)fm);
-        const bool is_flat = (flat >> fm) & 1u, is_kept = ((others >> fm) & 1u) && rank_fm < 16u;
+        const bool is_flat = (flat >> fm) & 1u, is_kept = ((others >> fm) & 1u) && rank_fm < (uint32_t)kSparseMaxVaried;
         if (is_flat || is_kept) {
             const uint32_t by = place >> 16, bx = place & 0xffffu;
             constexpr uint32_t kRgbr = 0x00020100u, kGbrg = 0x01000201u, kBrgb = 0x02010002u;
