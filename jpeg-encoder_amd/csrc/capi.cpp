@@ -1206,7 +1206,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     DecodeReport* report = (DecodeReport*)ctx->pinned;
     uint64_t* seg = (uint64_t*)((uint8_t*)ctx->pinned + 64);
     uint8_t* hdr = (uint8_t*)ctx->pinned + 64 + seg_bytes;
-    uint64_t max_size = 0, ubytes = 0;
+    uint64_t max_size = 0, ubytes = 0, total_size = 0;
     bool too_short = false;   // reported after the headers have been looked at, as the reference would
     for (size_t i = 0; i < n_images; ++i) {
         if (h_sizes[i] < skip) return fail(ctx, JEA_ERR_BAD_HEADER, "Failed to find SOI marker");
@@ -1216,10 +1216,11 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
         seg[2 * n_images + i] = ubytes;
         ubytes += (h_sizes[i] - skip + 15) / 16 * 16 + 16;
         if (h_sizes[i] - skip > max_size) max_size = h_sizes[i] - skip;
+        total_size += h_sizes[i] - skip;
     }
     if (mcus * 3 > 0x7fffffffull || max_size > (1ull << 34))
         return fail(ctx, JEA_ERR_INVALID_ARG, "decode: image or stream too large");
-    const DecodePlan plan = plan_entropy_decode(n_images, max_size, mcus);
+    const DecodePlan plan = plan_entropy_decode(n_images, max_size, mcus, total_size);
     const size_t subs = plan.subs_per_image;
     if ((rc = ensure(ctx, ctx->seg_offsets, seg_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->ustream, ubytes))) return rc;

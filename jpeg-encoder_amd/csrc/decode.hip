@@ -586,7 +586,7 @@ struct WriteTarget {
     uint32_t final_bit;      // ... at this bit position (relative to the group)
 };
 
-template <bool kPlanar>
+template <bool kPlanar, bool kFours>
 struct BlockWriter {
     uint32_t* acc;       // this thread's chunk buffer in LDS, all zero between chunks
     uint4* dst;          // chunk 0 of the current block
@@ -595,6 +595,39 @@ struct BlockWriter {
     uint32_t chunk;      // index of the chunk being assembled
     uint32_t mask;
     uint32_t dc;
+    // A thread's blocks follow one another, so their records do too: they leave four at a time, as one aligned
+    // 16-byte store (a 4-byte store per block is a write transaction per block at the L2, and those, not the bytes,
+    // were half of this pass's time on smooth pictures).  q0..q2: the `pending` records before the current one,
+    // oldest first when there are three; last_record: where the newest of them belongs.
+    // (in fours only where the launch has workgroups to spare: the few instructions it takes lengthen a thread's
+    // walk, which is all that counts when a single picture's workgroups have the GPU to themselves)
+    uint32_t q0 = 0, q1 = 0, q2 = 0, pending = 0;
+    uint32_t* last_record = nullptr;
+
+    __device__ __forceinline__ void flush_records() {
+        if (pending >= 1) last_record[0] = q2;
+        if (pending >= 2) last_record[-1] = q1;
+        if (pending >= 3) last_record[-2] = q0;
+        pending = 0;
+    }
+    __device__ __forceinline__ void put_record(uint32_t value) {
+        if (!kFours) {
+            *record_dst = value;
+            return;
+        }
+        const bool closes_four = ((uint32_t)(reinterpret_cast<uintptr_t>(record_dst) >> 2) & 3u) == 3u;
+        if (closes_four && pending == 3u) {
+            *reinterpret_cast<uint4*>(record_dst - 3) = make_uint4(q0, q1, q2, value);
+            pending = 0;
+        } else if (closes_four) {   // the thread's first records: the four began in another thread's blocks
+            *record_dst = value;
+            flush_records();
+        } else {
+            q0 = q1; q1 = q2; q2 = value;
+            ++pending;
+            last_record = record_dst;
+        }
+    }
 
     __device__ __forceinline__ void begin(uint4* chunk0, size_t stride, uint32_t* record) {
         dst = chunk0;
@@ -634,7 +667,7 @@ struct BlockWriter {
     __device__ __forceinline__ void end() {
         flush();
         if (kPlanar) {
-            *record_dst = dc | (mask << 16);
+            put_record(dc | (mask << 16));
         } else {
             for (uint32_t i = chunk + 1; i < 8; ++i) dst[i] = make_uint4(0, 0, 0, 0);
         }
@@ -643,7 +676,7 @@ struct BlockWriter {
 
 // Every symbol moves the position inside the block forward, so a block is at most 64 symbols of at
 // most 26 bits (a damaged one included) and the walk cannot leave the staged window.
-template <uint32_t W, bool kPlanar>
+template <uint32_t W, bool kPlanar, bool kFours>
 __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw, const StepTables& t, uint32_t* acc,
                                              uint32_t lum_mask, uint32_t sub, uint32_t state, WriteTarget& wt,
                                              uint32_t limit = 0xffffffffu) {
@@ -681,7 +714,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     bool finished = false, owning = false;
     uint32_t final_bit = 0;
     uint32_t trouble = 0;   // bit 6: an entry reaches past position 63; kStepBad: no code word -- in an own block
-    BlockWriter<kPlanar> bw;
+    BlockWriter<kPlanar, kFours> bw;
     bw.acc = acc;
     BitWindow<GroupWords<W, kWriteTail>> win(gw, p);
     for (;;) {
@@ -734,6 +767,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
             }
         }
     }
+    if (kPlanar && kFours) bw.flush_records();
     wt.error = (trouble & (64u | kStepBad)) != 0;
     wt.finished = finished;
     wt.final_bit = final_bit;
@@ -1089,7 +1123,7 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
 // stream held enough blocks.
 constexpr uint32_t kFoldGroups = 1024;
 
-template <uint32_t W, bool kPlanar, bool kFold, bool kRaw>
+template <uint32_t W, bool kPlanar, bool kFold, bool kRaw, bool kFours>
 __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* __restrict__ ustream,
                                                                 const uint64_t* __restrict__ ubase,
                                                                 const uint64_t* __restrict__ sizes,
@@ -1197,7 +1231,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     wt.final_bit = 0;
     if (!active || wt.block >= total_blocks) return;
 
-    write_blocks<W, kPlanar>(gw, t, acc + tid * kAccWords, lum_mask, tid, start_state, wt, limit);
+    write_blocks<W, kPlanar, kFours>(gw, t, acc + tid * kAccWords, lum_mask, tid, start_state, wt, limit);
     if (wt.error) {
         // a malformed symbol outranks a missing end marker, as in the serial order of checks
         const int32_t old = atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
@@ -1421,7 +1455,7 @@ void launch_build_step_tables(hipStream_t s, const uint8_t* d_data, const uint64
     build_step_tables_kernel<<<(unsigned)n_images, kThreads, 0, s>>>(d_data, d_scan_offsets, header_bytes, 0u, d_tables);
 }
 
-DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image) {
+DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image, size_t total_scan_bytes) {
     DecodePlan p;
     p.n_images = (uint32_t)n_images;
     p.n_chunks = (uint32_t)((max_scan_bytes + kChunkBytes - 1) / kChunkBytes);
@@ -1437,6 +1471,13 @@ DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mc
     }
     p.subs_per_image = (size_t)p.n_groups * kOwned;
     p.total_blocks = (uint32_t)(mcus_per_image * 3);
+    // Block records four at a time (BlockWriter::put_record): where the launch has workgroups with work to spare, and
+    // not for pictures full of detail, where a thread has few blocks.  Write pass, records singly / in fours:
+    // 256 smooth 1080p q=50 frames (1024 workgroups, 5 bits per block) 220 / 149 us, q=90 (4352; 21 bits) 879 / 813,
+    // eight photo-like 4K pictures (1440; 55 bits) 277 / 281.5, one smooth 4K picture (180) level.
+    if (total_scan_bytes == 0) total_scan_bytes = max_scan_bytes * n_images;
+    const uint64_t busy_groups = total_scan_bytes / ((uint64_t)kOwned * 4 * p.sub_words);
+    p.records_in_fours = busy_groups >= 256 && (uint64_t)total_scan_bytes * 8 < 40ull * p.total_blocks * n_images;
     return p;
 }
 
@@ -1491,12 +1532,17 @@ struct DecodeRun {
                                                                     tables_per_image ? 1u : 0u);
         }
     }
-    template <bool kPlanar, bool kFold, bool kRaw>
-    void write(uint32_t* check) const {
-        decode_write_kernel<W, kPlanar, kFold, kRaw><<<grid(), kThreads, 0, s>>>(
+    template <bool kPlanar, bool kFold, bool kRaw, bool kFours>
+    void write_launch(uint32_t* check) const {
+        decode_write_kernel<W, kPlanar, kFold, kRaw, kFours><<<grid(), kThreads, 0, s>>>(
             sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, p.total_blocks, d_tables, sc.sub_used, sc.sub_info,
             sc.grp_base, d_coefs, kPlanar ? sc.out_records : nullptr, sc.mode.lum_mask, d_status, sc.grp_sum, sc.sub_end,
             sc.grp_pending, check, source(), tables_per_image ? 1u : 0u);
+    }
+    template <bool kPlanar, bool kFold, bool kRaw>
+    void write(uint32_t* check) const {
+        if (kPlanar && p.records_in_fours) write_launch<kPlanar, kFold, kRaw, kPlanar>(check);
+        else write_launch<kPlanar, kFold, kRaw, false>(check);
     }
     // The unstuffed-copy decoder is the fall-back for streams that need repair rounds: it always scans in a launch
     // of its own.

@@ -82,7 +82,7 @@ struct StepTableT {
 // Table sizes are LDS: with 23 KB of tables three workgroups of the write pass fit a compute unit, with 34 KB
 // (eleven index bits for the DC tables too) only two, and a 4K picture of noise decoded in 0.78 instead of 0.70 ms.
 using StepTableDc = StepTableT<9, 128>;    // DC codes are at most 11 bits long
-using StepTableAc = StepTableT<11, 256>;   // the Annex K AC codes beyond 11 bits fit eight 32-entry sub-tables
+using StepTableAc = StepTableT<10, 320>;   // the Annex K AC codes beyond 10 bits fit five 64-entry sub-tables
 struct StepClass {
     StepTableDc dc;
     StepTableAc ac;
@@ -211,8 +211,10 @@ struct DecodePlan {
     uint32_t n_groups = 0;      // workgroups covering the longest scan
     size_t subs_per_image = 0;  // sub-sequence records per image
     uint32_t total_blocks = 0;  // block-channels per image
+    bool records_in_fours = false;   // the write pass stores block records as aligned 16-byte fours
 };
-DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image);
+// total_scan_bytes: of all images together; 0 = not known
+DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image, size_t total_scan_bytes = 0);
 
 // Caller-provided scratch; n = images, subs = DecodePlan::subs_per_image.
 struct DecodeScratch {
