@@ -579,8 +579,10 @@ def config_c5(job):
                 "traffic": inverse_traffic, "avg_launch_us": round(ph[3] * 1e3, 1), "algorithmic_bytes_per_launch": int(inv_bytes),
                 "standard_layout_equivalent_GBps": round(std_bytes / (ph[3] * 1e-3) / 1e9, 1),
                 "bound_note": "3 B/px written + 12 B/MCU of block records read; the chunks of blocks with detail come on top. "
-                              "Stores and the latency of a workgroup's record -> barrier -> store chain bind it, not arithmetic: "
-                              "most MCUs of these frames are one colour. 6 B/px of coefficients read + 3 B/px written, the "
+                              "The stores bind it, with the record reads mixed into them, not arithmetic (most MCUs of these frames "
+                              "are one colour): the same rows written after one record load per MCU and nothing else run at "
+                              "4.75 TB/s on this GPU, without the loads at 5.55, a linear fill at 6.85 (tools/store_patterns.hip). "
+                              "6 B/px of coefficients read + 3 B/px written, the "
                               "figure for the standard layout, would read as `standard_layout_equivalent_GBps`",
                 "other_kernels": {
                     "decode_write_kernel(+scan)": {"us": round(ph[2] * 1e3, 1), "algorithmic_bytes": int(stream_bytes + 6 * px),
@@ -588,7 +590,8 @@ def config_c5(job):
                                                    "note": "stream bytes read + 6 B/px of coefficients written is the standard layout's figure; "
                                                            "inside jea_decode_batch the pass stores one 4-byte record per block plus the chunks "
                                                            "that hold a non-zero AC coefficient, far fewer bytes, so the equivalent rate may exceed "
-                                                           "the HBM peak; bound by the latency of the serial walks, not by memory"},
+                                                           "the HBM peak; bound by the latency of the serial walks and by the L2's write transactions (a 16-byte "
+                                                           "chunk or four records each), not by bytes"},
                     "decode_sync_kernel x2": {"us": round(ph[1] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes),
                                               "note": "the stuffed bytes are dropped while the raw scan is staged: no unstuffing pass"}}}
     cpu = None

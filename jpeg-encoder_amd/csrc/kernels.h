@@ -79,8 +79,10 @@ struct StepTableT {
     uint32_t fast[1 << kFastBitsT];
     uint32_t slow[kSlowEntriesT];
 };
-// Table sizes are LDS: with 23 KB of tables three workgroups of the write pass fit a compute unit, with 34 KB
-// (eleven index bits for the DC tables too) only two, and a 4K picture of noise decoded in 0.78 instead of 0.70 ms.
+// Table sizes are LDS, and LDS is what limits the workgroups per compute unit of the passes that walk the stream.
+// Eleven index bits for the AC tables (23 KB of tables): three workgroups; ten (15 KB): four, and the synchronisation
+// rounds of a batch run 13-26 % quicker, although fewer symbol + end-of-block pairs fit an entry; eleven bits for the
+// DC tables too (34 KB): two, and a 4K picture of noise decoded in 0.78 instead of 0.70 ms.
 using StepTableDc = StepTableT<9, 128>;    // DC codes are at most 11 bits long
 using StepTableAc = StepTableT<10, 320>;   // the Annex K AC codes beyond 10 bits fit five 64-entry sub-tables
 struct StepClass {
