@@ -1467,7 +1467,11 @@ DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mc
         p.sub_words = w;
         p.n_groups = (uint32_t)((subs + kOwned - 1) / kOwned);
         if (p.n_groups == 0) p.n_groups = 1;
+#ifdef JEA_PLAN_MIN_GROUPS   // experiments: tools/build_variant.sh <name> -DJEA_PLAN_MIN_GROUPS=<n>
+        if ((uint64_t)p.n_groups * n_images >= JEA_PLAN_MIN_GROUPS) break;
+#else
         if ((uint64_t)p.n_groups * n_images >= 512) break;
+#endif
     }
     p.subs_per_image = (size_t)p.n_groups * kOwned;
     p.total_blocks = (uint32_t)(mcus_per_image * 3);
