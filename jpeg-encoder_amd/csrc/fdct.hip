@@ -447,10 +447,10 @@ __global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_row
 #pragma unroll
                 for (int p = 0; p < 8; ++p) f[p] = px[3 * p + ch] - 128.0f;
             } else {
-                // One test per pixel row: the smallest fraction of the eight values against the window (a branch per
-                // value costs the wave some ten cycles each, taken or not).  Only where some lane's row has a value
-                // near a tie (46 % of a wave's luminance rows, 10 % of the others) are the values looked at one by
-                // one, and the literal formula runs for those that are.  2 % on the kernel.
+                // One test per pixel row: the smallest fraction of the eight values against the window (four min3 and
+                // a compare instead of eight half-rate compares and eight branches).  Only where some lane's row has a
+                // value near a tie (46 % of a wave's luminance rows, 10 % of the others) are the values looked at one
+                // by one, and the literal formula runs for those that are.  2 % on the kernel.
                 float fr[8];
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
