@@ -458,7 +458,8 @@ __global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_row
                     fr[p] = __builtin_amdgcn_fractf(qv);
                     f[p] = qv - fr[p];
                 }
-                const float smallest = fminf(min3(min3(fr[0], fr[1], fr[2]), fr[3], fr[4]), min3(fr[5], fr[6], fr[7]));
+                // (min3 throughout: fminf would first canonicalise both operands, two more instructions)
+                const float smallest = min3(min3(min3(fr[0], fr[1], fr[2]), fr[3], fr[4]), min3(fr[5], fr[6], fr[7]), fr[7]);
                 if (__builtin_expect(__any(smallest < ci[ch].window), 0)) {
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
