@@ -1078,9 +1078,11 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
     ImageLevel lvl{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity, (uint32_t)header_len + 2 * eoi, d_status};
     lvl.prev_offset = d_prev_offset;
     lvl.prev_size = d_prev_size;
+    if (sc.wait_before_offsets != nullptr) (void)hipStreamWaitEvent(s, sc.wait_before_offsets, 0);
     scan_tiles_ff_kernel<<<n, 1024, 0, s>>>(sc.tile_bits, (const uint4*)sc.tile_ff8, n_tiles, sc.tile_base,
                                             sc.tile_ffbase, sc.img_bits, sc.img_ff, lvl);
     if (n > 1) scan_images_kernel<<<1, 1024, 0, s>>>(n, sc.img_ff, lvl);
+    if (sc.record_after_offsets != nullptr) (void)hipEventRecord(sc.record_after_offsets, s);
     pack_stuff_kernel<false><<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits,
                                                           (const uint4*)sc.tile_ff8, sc.tile_base, sc.tile_ffbase,
                                                           d_offsets, d_sizes, header, (uint32_t)header_len, eoi, d_out,

@@ -168,6 +168,11 @@ struct EntropyScratch {
     hipEvent_t* marks = nullptr;   // timing marks (null = none): launch_entropy_encode records marks[0] after the
                                    // bit-string kernel; the caller records what comes before and after
     OptimalHuffman optimal;
+    // Passes of one batch on two streams (jea_encode_batch_async): what the stream waits for before the kernels that
+    // need the file offset the pass before this one ended at (null = nothing to wait for)
+    hipEvent_t wait_before_offsets = nullptr;
+    // ... and what it records once this pass's own offsets and sizes are final (before its files are written)
+    hipEvent_t record_after_offsets = nullptr;
 };
 
 // d_status_to_clear (may be null): status word of the encode pass this launch opens; the kernel zeroes it.

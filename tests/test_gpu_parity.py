@@ -745,6 +745,40 @@ def test_encode_batch_in_passes_under_a_scratch_budget(jea, po):
             c.close()
 
 
+def test_encode_batch_in_pieces_on_two_streams(jea, po):
+    """From 128 images on, a batch goes through as pieces of 64 that alternate over two streams of the context; files,
+    offsets and sizes are those of a single pass.  131 images: two whole pieces and one of three; then a smaller batch and
+    a larger one on the same context, and a capacity that the last piece exceeds."""
+    import torch
+
+    b = jea.binding
+    w, h, quality = 72, 40, 85
+    lum, chrom = b.quant_tables(quality)
+    distinct = [po.gen_image(w, h, i % 3 if i % 3 < 2 else 0, 900 + i) for i in range(9)]
+    want = [po.encode(im, quality) for im in distinct]
+    c = jea.Context(0)
+    try:
+        for n in (131, 40, 260):
+            src = [(5 * i + i // 7) % 9 for i in range(n)]
+            d_rgb = c.to_device(np.stack([distinct[k] for k in src]).reshape(-1))
+            cap = sum(len(want[k]) + 64 for k in src)
+            out = torch.full((cap,), 0xA5, dtype=torch.uint8, device=c.tdev)
+            _, off, size = c.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=cap, d_out=out)
+            host = out.cpu().numpy()
+            at = 0
+            for i, k in enumerate(src):
+                assert int(off[i]) == at and int(size[i]) == len(want[k]), (n, i)
+                assert host[at: at + len(want[k])].tobytes() == want[k], (n, i)
+                at = (at + len(want[k]) + 63) // 64 * 64
+            if n == 131:   # one byte less than the last piece needs
+                short = int(off[n - 1]) + int(size[n - 1]) - 1
+                with pytest.raises(b.JeaError) as e:
+                    c.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=short, d_out=out[:short])
+                assert e.value.code == 3
+    finally:
+        c.close()
+
+
 def test_phase_timing(ctx, po, jea):
     b = jea.binding
     w, h, quality = 640, 480, 75
