@@ -506,7 +506,9 @@ def config_c3(job):
     ph = ctx.last_phase_ms()
     ctx.set_profiling(False)
     roofline["pipeline_phase_us"] = {"forward_transform": round(ph[0] * 1e3, 1), "bit_strings": round(ph[1] * 1e3, 1),
-                                     "scans_pack_stuff": round(ph[2] * 1e3, 1)}
+                                     "scans_pack_stuff": round(ph[2] * 1e3, 1),
+                                     "note": "the same batch as one pass on one stream, which is how a profiled call runs; the timed "
+                                             "calls run as pieces of 64 frames on two streams of the context, transform beside entropy coding"}
     cpu = None
     if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_encode_baseline(po, frames[:64], QUALITY, 192, CPU_THREADS)
