@@ -524,6 +524,7 @@ void jea_destroy(jea_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->lane_stream) (void)hipStreamSynchronize(ctx->lane_stream);   // it works on the scratch freed below
     for (DeviceBuffer* b : {&ctx->coefs, &ctx->masks, &ctx->len16, &ctx->slots, &ctx->tile_bits, &ctx->tile_base, &ctx->tile_ff,
                             &ctx->tile_ffbase, &ctx->img_words, &ctx->unstuffed, &ctx->stage_in, &ctx->stage_out,
                             &ctx->seg_offsets, &ctx->out_offsets, &ctx->out_sizes, &ctx->stream_copy, &ctx->small,
