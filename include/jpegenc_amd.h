@@ -162,10 +162,11 @@ int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16
 /* Same work, asynchronous: enqueues on the context's stream and returns.
  * d_offsets / d_sizes (n_images x uint64 each) and d_status (one int32: 0 or a
  * JEA_ERR_* code) are device buffers filled by the kernels; read them after
- * jea_synchronize() or from later work on the same stream.  Batches of 128 images and more run as pieces of 64
- * that alternate between the context's stream and a second stream of its own (the transform of one piece beside
- * the entropy coding of the one before); that stream starts after what is already on the context's stream and the
- * context's stream ends the call, so the ordering a caller sees is that of a single stream. */
+ * jea_synchronize() or from later work on the same stream.  On the context's own stream, batches of 128 images
+ * and more run as pieces of 64 that alternate between that stream and a second stream of the context (the
+ * transform of one piece beside the entropy coding of the one before); the second stream starts after what is
+ * already on the first and the first ends the call, so the ordering a caller sees is that of a single stream.
+ * On a stream given with jea_set_stream everything stays on that stream. */
 int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
                            const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out,
                            size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);

@@ -1000,7 +1000,10 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
     if (pass > n_images) pass = n_images;
     // (a large batch runs as pieces of kLanePiece images on two streams, see below: scratch for two pieces)
     constexpr size_t kLanePiece = 64;
-    const bool two_lanes = pass >= 2 * kLanePiece && n_images >= 2 * kLanePiece && !ctx->profiling && !ctx->optimal_huffman;
+    // (only on the context's own stream: a caller's stream may have another priority, and streams of different
+    // priorities that wait for each other's events are what once stopped a GPU in our experiments)
+    const bool two_lanes = pass >= 2 * kLanePiece && n_images >= 2 * kLanePiece && !ctx->profiling && !ctx->optimal_huffman &&
+                           ctx->stream == ctx->own_stream;
     if (two_lanes) pass = 2 * kLanePiece;
     int rc;
     if ((rc = ensure(ctx, ctx->coefs, pass * mcus * 3 * 64 * sizeof(int16_t)))) return rc;
