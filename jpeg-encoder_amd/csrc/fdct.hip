@@ -1268,7 +1268,11 @@ void launch_idct_dequant(hipStream_t s, const int16_t* d_coefs, size_t n_images,
     mostly_single_colours = false;
 #endif
     if (d_records != nullptr && d_group_list != nullptr && mostly_single_colours && width % 8 == 0 &&
-        total_groups >= 8192 && total_groups < (1ull << 32)) {
+#ifdef JEA_SPARSE_FROM_GROUPS   // experiments: tools/build_variant.sh <name> -DJEA_SPARSE_FROM_GROUPS=<n>
+        total_groups >= JEA_SPARSE_FROM_GROUPS && total_groups < (1ull << 32)) {
+#else
+        total_groups >= 4096 && total_groups < (1ull << 32)) {
+#endif
         (void)hipMemsetAsync(d_group_list, 0, sizeof(uint32_t), s);
         const dim3 grid_sparse((grid.x + kSparseWaves - 1) / kSparseWaves, (unsigned)n_images);
         idct_sparse_kernel<<<grid_sparse, 64 * kSparseWaves, 0, s>>>(d_coefs, d_records, width, height, bw, n_mcu, image_bytes, q,

@@ -160,7 +160,7 @@ def test_decode_batch_whose_detailed_groups_overflow_the_inverse_transforms_list
 
 @pytest.mark.parametrize("mapper", [0, 1])
 def test_decode_batch_of_many_small_smooth_pictures_with_both_mappers(po, jea, mapper):
-    """Thousands of small pictures in one call reach the inverse kernel for single-colour groups (8192 groups of 64
+    """Thousands of small pictures in one call reach the inverse kernel for single-colour groups (4096 groups of 64
     MCUs, small files) too -- with the YCbCr mapper and with the pass-through mapper (colour_mapping.cpp:16-42), and
     with a last group of each picture that is not full (120 MCUs: groups of 64 and 56)."""
     import torch

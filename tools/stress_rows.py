@@ -1,5 +1,5 @@
 """Randomised run on the GPU box aimed at the kernels for pictures whose sides are multiples of 8: batches through
-jea_encode_batch (row-lane forward kernel, one to six units per wave) and jea_decode_batch (from 8192 groups of 64 MCUs
+jea_encode_batch (row-lane forward kernel, one to six units per wave) and jea_decode_batch (from 4096 groups of 64 MCUs
 on and where nine files in ten are small, the inverse kernel for single-colour groups and its list) against the oracle.
 usage: stress_rows.py [cases] [seed]"""
 import concurrent.futures
@@ -44,7 +44,7 @@ for i in range(cases):
     w = 8 * int(rng.randint(8, 40 if small else 200))
     h = 8 * int(rng.randint(1, 24 if small else 120))
     groups = ((w // 8) * (h // 8) + 63) // 64
-    n = int(rng.randint(8192 // groups, 2 * 8192 // groups + 2)) if small else int(rng.randint(1, max(2, int(2.5e7 / (w * h)))))
+    n = int(rng.randint(4096 // groups, 4 * 4096 // groups + 2)) if small else int(rng.randint(1, max(2, int(2.5e7 / (w * h)))))
     n = max(1, min(n, int(4e7 / (w * h))))
     q = int(rng.choice([10, 50, 50, 75, 90, 100]))
     kinds = rng.choice([0, 2, 3, 4] if small else [0, 1, 2, 3, 4], size=rng.randint(1, 4))
@@ -58,7 +58,7 @@ for i in range(cases):
     blob = out.cpu().numpy()
     ok = all(blob[int(off[k]): int(off[k]) + int(size[k])].tobytes() == want[src[k]] for k in range(n))
     small_files = sum(len(want[s]) - 607 < 2.2 * (w // 8) * (h // 8) for s in src)
-    routed += n * groups >= 8192 and 10 * small_files >= 9 * n
+    routed += n * groups >= 4096 and 10 * small_files >= 9 * n
     dec = ctx.decode_batch(out, [int(o) for o in off], [int(s) for s in size], w, h, lum, chrom).cpu().numpy().reshape(n, h, w, 3)
     ref = list(pool.map(lambda k: po.decode(want[k], w, h, q), range(distinct)))
     ok_d = all(np.array_equal(dec[k], ref[src[k]]) for k in range(n))

@@ -46,7 +46,7 @@ for i in range(cases):
     h = int(rng.randint(8, 260))
     mcus = (w // 8) * ((h + 7) // 8)
     groups = (mcus + 63) // 64
-    n = int(rng.randint(8192 // groups + 1, 2 * 8192 // groups + 3))
+    n = int(rng.randint(4096 // groups + 1, 4 * 4096 // groups + 3))
     n = max(1, min(n, int(6e7 / (w * h))))
     q = int(rng.choice([25, 50, 50, 60, 75]))
     mapper = int(rng.randint(2))
@@ -70,7 +70,7 @@ for i in range(cases):
     po.set_mapper(0)
     src = [int(rng.randint(distinct)) for _ in range(n)]
     small_files = sum(len(files[s]) - 607 < limit * mcus for s in src)
-    routed += n * groups >= 8192 and 10 * small_files >= 9 * n
+    routed += n * groups >= 4096 and 10 * small_files >= 9 * n
     blob = np.frombuffer(b"".join(files[s] for s in src), np.uint8)
     sizes = [len(files[s]) for s in src]
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
