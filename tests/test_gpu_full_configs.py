@@ -196,3 +196,29 @@ def test_decode_batch_of_many_small_smooth_pictures_with_both_mappers(po, jea, m
     finally:
         po.set_mapper(0)
         ctx.close()
+
+
+def test_decode_batch_whose_block_records_leave_in_fours_at_every_alignment(ctx, po, jea):
+    """Where a batch has work to spare the write pass stores four block records at a time, at 16-byte aligned
+    addresses.  459 blocks per picture (an odd number) move every picture's records to another alignment, and the
+    sub-sequences' first and last blocks fall anywhere: 10 400 small pictures of four kinds against the oracle."""
+    import torch
+
+    w, h, q, n = 136, 72, 50, 10400
+    lum, chrom = jea.binding.quant_tables(q)
+    sources = []
+    for k in range(4):
+        img = po.gen_image(w, h, 0, 700 + k)
+        img[8 * k: 8 * k + 16, 24: 24 + 8 * (k + 1)] = np.random.RandomState(k).randint(0, 256, (16, 8 * (k + 1), 3))
+        sources.append(img)
+    files = [po.encode(sx, q) for sx in sources]
+    total = sum(len(files[i % 4]) - 607 for i in range(n))
+    assert total >= 256 * 240 * 4 * 16 and total * 8 < 40 * 459 * n, total      # the condition for records in fours
+    want = [torch.from_numpy(po.decode(f, w, h, q).copy()).to(ctx.tdev) for f in files]
+    kind = (np.arange(n) * 7 // 3) % 4
+    sizes = np.array([len(files[k]) for k in kind], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    d_jpeg = ctx.to_device(np.frombuffer(b"".join(files[k] for k in kind), np.uint8))
+    rgb = ctx.decode_batch(d_jpeg, offs, sizes, w, h, lum, chrom).view(n, h, w, 3)
+    wrong = [i for i in range(n) if not torch.equal(rgb[i], want[kind[i]].view(h, w, 3))]
+    assert not wrong, (len(wrong), wrong[:8])
