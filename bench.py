@@ -13,9 +13,17 @@
                 protocol: transform, exchange of the DC predictors, bit strings, exchange of the bit counts,
                 pack and stuff, gather of the segments on rank 0 (RCCL between GPUs).
   c5            1024 JPEG files of 1920x1080 at q=50 decoded, sharded by image; a step decodes the rank's share.
-For N > 1 the driver launches one rank per GPU with torch.distributed.run.  There is no data-path collective
-except c4's exchanges; the reported value is all ranks' pixels over the slowest rank's time (weak scaling for
-c2, strong for c3-c5, whose total work is fixed).
+N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets RANK / WORLD_SIZE / MASTER_*) this process
+is one rank.  Without one, `--gpus N` starts the N ranks itself: before anything touches a GPU the process runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child, lets rank 0's
+JSON line through and exits with the child's code.  Every line says how many ranks took part (`ranks_seen`, a sum of
+ones over the process group) and over what (`comm_backend`).  There is no data-path collective except c4's
+exchanges; the reported value is all ranks' pixels over the slowest rank's time (weak scaling for c2, strong for
+c3-c5, whose total work is fixed).
+
+The default run (c2) also carries, under `other_measurements`, the other configurations at their full sizes: with one
+rank c3 and c5 (1024 frames each), with several ranks c4 (the stripe protocol with its collectives, file hash
+checked) -- each with the steps and warm-up of its own defaults; none of them is `value`.
 
 Timing: after an untimed ramp and W warm-up steps, regions of exactly K steps each are timed, every one
 bracketed by a barrier and a device synchronisation on both sides; as many regions as fit 50 ms (one, when K
@@ -33,6 +41,8 @@ import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -89,6 +99,7 @@ class Job:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
+            # a launcher's environment decides; n_gpus and ranks_seen in the line say what actually ran
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, self.world), file=sys.stderr)
         self.dist = None
         n_devices = torch.cuda.device_count()
@@ -111,6 +122,10 @@ class Job:
         self.binding = self.pkg.binding
         self.dev = torch.device("cuda", self.device_index)
         self.comm_device = self.dev if self.backend == "nccl" else "cpu"
+        # how many ranks really take part: every rank adds a one
+        self.ranks_seen = int(round(self.sum_over_ranks(1)))
+        self.comm_name = "none (one process)" if self.dist is None else \
+            ("nccl (RCCL)" if self.backend == "nccl" else self.backend)
 
     def barrier(self, sync):
         if self.dist is not None:
@@ -166,8 +181,10 @@ class Job:
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+        out["ranks_seen"] = self.ranks_seen
+        out["comm_backend"] = self.comm_name
         if self.rank == 0:
-            print(json.dumps(out))
+            print(json.dumps(out), flush=True)
 
 
 def region_stats(regions):
@@ -469,11 +486,12 @@ def rank_frames(job, po):
         return np.stack(list(tp.map(lambda i: po.gen_image(FW, FH, 1 if i % 64 == 63 else 0, 1234 + i), mine))), mine
 
 
-def config_c3(job):
+def config_c3(job, steps=None, warmup=None, with_cpu=True):
     import numpy as np
     import pyoracle as po
 
     args, torch, binding = job.args, job.torch, job.binding
+    steps, warmup = (args.steps if steps is None else steps), (args.warmup if warmup is None else warmup)
     QUALITY = 90
     ctx = job.pkg.Context(job.device_index)
     lum, chrom = binding.quant_tables(QUALITY)
@@ -496,8 +514,8 @@ def config_c3(job):
     for i in sample:
         if o["out"][int(offs[i]): int(offs[i] + sizes[i])].cpu().numpy().tobytes() != want[i]:
             raise SystemExit("bench: GPU JPEG %d differs from the oracle's; refusing to report a number" % i)
-    seconds, regions = job.timed(step, ctx.synchronize)
-    value = job.sum_over_ranks(args.steps * n * FW * FH) / seconds / 1e6
+    seconds, regions = job.timed(step, ctx.synchronize, steps, warmup)
+    value = job.sum_over_ranks(steps * n * FW * FH) / seconds / 1e6
     roofline, _ = forward_kernel_roofline(job, ctx, [pool.whole], None, FW, FH, lum, chrom, n)
     roofline["bound"] = "valu"
     roofline["traffic"] = None
@@ -510,10 +528,10 @@ def config_c3(job):
                                      "note": "the same batch as one pass on one stream, which is how a profiled call runs; the timed "
                                              "calls run as pieces of 64 frames on two streams of the context, transform beside entropy coding"}
     cpu = None
-    if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+    if job.rank == 0 and job.world == 1 and with_cpu and not args.no_cpu_baseline:
         cpu = cpu_encode_baseline(po, frames[:64], QUALITY, 192, CPU_THREADS)
     out = {"metric": "encode MPix/s (q=90)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
+           "steps": steps, "warmup": warmup, "ms_per_step": round(seconds / steps * 1e3, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic RGB8 frames (seeds 1234+i; every 64th uniform noise), resident in HBM",
            "config": {"workload": "batch of %d 1920x1080 frames at q=90, sharded by image, %d per rank, one encode call per step"
@@ -525,11 +543,12 @@ def config_c3(job):
     return out
 
 
-def config_c5(job):
+def config_c5(job, steps=None, warmup=None, with_cpu=True):
     import numpy as np
     import pyoracle as po
 
     args, torch, binding = job.args, job.torch, job.binding
+    steps, warmup = (args.steps if steps is None else steps), (args.warmup if warmup is None else warmup)
     QUALITY = 50
     ctx = job.pkg.Context(job.device_index)
     lum, chrom = binding.quant_tables(QUALITY)
@@ -554,8 +573,8 @@ def config_c5(job):
     for i in sample:
         if not np.array_equal(got[i].cpu().numpy(), po.decode(files[i], FW, FH, QUALITY)):
             raise SystemExit("bench: GPU decode of file %d differs from the oracle's; refusing to report a number" % i)
-    seconds, regions = job.timed(step, ctx.synchronize)
-    value = job.sum_over_ranks(args.steps * n * FW * FH) / seconds / 1e6
+    seconds, regions = job.timed(step, ctx.synchronize, steps, warmup)
+    value = job.sum_over_ranks(steps * n * FW * FH) / seconds / 1e6
     ctx.set_profiling(True)
     acc = [0.0] * 4
     for _ in range(5):
@@ -597,7 +616,7 @@ def config_c5(job):
                     "decode_sync_kernel x2": {"us": round(ph[1] * 1e3, 1), "algorithmic_bytes": int(2 * stream_bytes),
                                               "note": "the stuffed bytes are dropped while the raw scan is staged: no unstuffing pass"}}}
     cpu = None
-    if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+    if job.rank == 0 and job.world == 1 and with_cpu and not args.no_cpu_baseline:
         t0 = time.perf_counter()
         for i in sample:
             po.decode(files[i], FW, FH, QUALITY)
@@ -610,7 +629,7 @@ def config_c5(job):
                "sample": "%d decodes of 1920x1080 q=50 files, one thread, oracle/jpeg_oracle.c" % len(sample),
                "all_cores": {"value": round(allc, 2), "unit": "MPix/s", "cores": CPU_THREADS, "cpu_model": cpu_model()}}
     out = {"metric": "decode MPix/s (q=50)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
+           "steps": steps, "warmup": warmup, "ms_per_step": round(seconds / steps * 1e3, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "JPEG files of synthetic frames (seeds 1234+i; every 64th uniform noise) encoded at q=50 by this library, resident in HBM",
            "config": {"workload": "batched decode of %d 1920x1080 q=50 JPEG files, sharded by image, %d per rank, one decode call per step"
@@ -623,11 +642,12 @@ def config_c5(job):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def config_c4(job):
+def config_c4(job, steps=None, warmup=None, with_cpu=True):
     import numpy as np
     import pyoracle as po
 
     args, torch, binding = job.args, job.torch, job.binding
+    steps, warmup = (args.steps if steps is None else steps), (args.warmup if warmup is None else warmup)
     stripes = importlib.import_module("jpeg-encoder_amd.stripes")
     W = H = args.c4_size
     QUALITY = 75
@@ -668,15 +688,15 @@ def config_c4(job):
                 raise SystemExit("bench: striped file differs from the oracle's; refusing to report a number")
             checked = "oracle, byte for byte"
     # no time-based ramp here: a step contains collectives, so every rank must run the same number of steps
-    seconds, regions = job.timed(step, ctx.synchronize, ramp=0.0)
-    value = args.steps * W * H / seconds / 1e6
+    seconds, regions = job.timed(step, ctx.synchronize, steps, warmup, ramp=0.0)
+    value = steps * W * H / seconds / 1e6
     ctx.set_profiling(False)
     mcus = binding.n_mcu(W, y1 - y0)
     roofline, _ = forward_kernel_roofline(job, ctx, [d_rgb], None, W, y1 - y0, lum, chrom, 1)
     roofline["bound"] = "valu"
     roofline["traffic"] = None
     cpu = None
-    if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+    if job.rank == 0 and job.world == 1 and with_cpu and not args.no_cpu_baseline:
         sample = po.gen_image(W, min(H, 1024), 0, 1234)
         t0 = time.perf_counter()
         po.encode(sample, QUALITY)
@@ -684,7 +704,7 @@ def config_c4(job):
                "kind": "port", "sample": "one encode of the top %d rows of the image, one thread, oracle/jpeg_oracle.c "
                                          "(one image: only the single-thread figure is meaningful)" % sample.shape[0]}
     out = {"metric": "encode MPix/s (q=75)", "value": round(value, 1), "unit": "MPix/s", "n_gpus": job.world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 4),
+           "steps": steps, "warmup": warmup, "ms_per_step": round(seconds / steps * 1e3, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic smooth RGB8 (seed 1234), each rank's stripe resident in HBM",
            "config": {"workload": "single %dx%d image at q=75 as %d MCU-row stripe(s), one per rank; per step: transform, "
@@ -696,6 +716,26 @@ def config_c4(job):
            "roofline": roofline, "cpu_baseline": cpu}
     ctx.close()
     return out
+
+
+def embedded(line):
+    """A configuration's own line as an entry of another line's other_measurements."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "data", "config", "roofline")
+    return {k: line[k] for k in keep if k in line}
+
+
+def run_as_ranks(n):
+    """`--gpus n` outside a launcher: the n ranks run as a child job under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1).  This process has made no GPU call and makes none: it waits and hands on the
+    child's exit code; the ranks inherit stdout, so rank 0's JSON line appears as if printed here."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -717,16 +757,29 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=0.1,
                     help="untimed steps before the warm-up, for the GPU clocks (0 for counter-collection runs)")
     ap.add_argument("--quick", action="store_true", help="c2: only the headline measurement and the roofline")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="c2: leave out the c3/c5 (one rank) and c4 (several ranks) measurements under other_measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=48, help="c2: images of the single-thread CPU sample")
     args = ap.parse_args()
-    defaults = {"c2": (2000, 200), "c3": (10, 2), "c4": (10, 2), "c5": (10, 2)}[args.config]
+    defaults_of = {"c2": (2000, 200), "c3": (10, 2), "c4": (10, 2), "c5": (10, 2)}
+    defaults = defaults_of[args.config]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
         args.warmup = defaults[1]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(run_as_ranks(args.gpus))      # nothing has touched a GPU yet; this process only relays
     job = Job(args)
     out = {"c2": config_c2, "c3": config_c3, "c4": config_c4, "c5": config_c5}[args.config](job)
+    if args.config == "c2" and not args.quick and not args.no_other_configs:
+        # the other configurations at full size, each at its own default steps / warm-up; never `value`
+        extra = out.setdefault("other_measurements", {})
+        if job.world == 1:
+            extra["c3_batch_of_1024_1080p_q90"] = embedded(config_c3(job, *defaults_of["c3"], with_cpu=False))
+            extra["c5_decode_of_1024_1080p_q50"] = embedded(config_c5(job, *defaults_of["c5"], with_cpu=False))
+        else:
+            extra["c4_16384x16384_as_stripes"] = embedded(config_c4(job, *defaults_of["c4"], with_cpu=False))
     job.finish(out)
 
 

@@ -81,6 +81,8 @@ int jea_set_scratch_budget(jea_ctx* ctx, size_t bytes);
  *     forward transform kernel | bit-string kernel | scans + pack-and-stuff kernel;
  *   decode (jea_decode_batch, jea_decode_host, jea_entropy_decode): 4 phases --
  *     unstuffing | the two synchronisation rounds | scan + write pass | inverse transform kernel.
+ * A decode whose stream the two standard rounds do not settle (it is decoded again by the variant with repair
+ * rounds) reports no phases: jea_last_phase_ms then fails as if no profiled call had been made.
  * Events between kernels cost a little; leave profiling off when measuring throughput. */
 int jea_set_profiling(jea_ctx* ctx, int on);
 int jea_last_phase_ms(jea_ctx* ctx, float* ms, size_t capacity, size_t* n_phases);
@@ -179,14 +181,23 @@ int jea_encode_batch_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, 
  * library -- one copy per GPU, held until the process ends -- so the call makes no
  * hipMalloc / hipFree and never synchronises.  Limits:
  *   - jea_static_scratch_needed(n_images, width, height) must not exceed
- *     JEA_STATIC_SCRATCH_BYTES (one 1920x1080 image needs 33.5 MB; the need grows
+ *     JEA_STATIC_SCRATCH_BYTES (one 1920x1080 image needs 33.3 MB; the need grows
  *     with n_images * MCUs); larger jobs get JEA_ERR_CAPACITY and a message that
  *     states both numbers, and nothing is enqueued;
- *   - all contexts of a GPU share that GPU's buffer: calls whose GPU work overlaps
- *     on one GPU (two contexts, or two streams) race.  Calls on one stream, one
- *     after the other, are fine: nothing in the buffer has to survive or to be
- *     cleared between calls. */
+ *   - all contexts of a GPU share that GPU's buffer.  The library keeps its users
+ *     apart: each call's kernels wait (an event of the GPU, no host wait, no
+ *     allocation) for the kernels of the call that used the buffer before, from
+ *     whichever context, stream or host thread that came -- so such calls never
+ *     overlap on a GPU, they queue.  The exception is a stream under HIP graph
+ *     capture, where an event cannot order work outside the graph: launches of
+ *     graphs that contain this call, and other calls of it on the same GPU, must
+ *     not overlap, or they race on the buffer.  Nothing in the buffer has to
+ *     survive or to be cleared between calls;
+ *   - the buffer costs JEA_STATIC_SCRATCH_BYTES of memory on every GPU that a
+ *     process with this library loaded uses, whether or not the call is made. */
 #define JEA_STATIC_SCRATCH_BYTES (48u << 20)
+/* The same number from the loaded library (for bindings that cannot read the macro). */
+size_t jea_static_scratch_bytes(void);
 size_t jea_static_scratch_needed(size_t n_images, uint16_t width, uint16_t height);
 int jea_encode_batch_static_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width,
                                   uint16_t height, const uint16_t lum_q[64], const uint16_t chr_q[64],
@@ -353,11 +364,14 @@ int jea_huffman_decode_block(jea_ctx* ctx, uint64_t start_bit, int is_luminance,
 /* HuffmanEncoder::applyFinalEncoding / removeFinalEncoding (entropy_encoder.cpp:696-712, 715-866): the
  * final-encoding step on the run-length form of one block-channel, the level at which the reference lets a
  * subclass of EntropyEncoder replace the coder (entropy_encoder.hpp:50-51).
- * Encode: the DC difference and then every (run, value) entry as given; (0, 0) is the end-of-block code,
- * (15, 0) the zero-run code, another entry with value 0 fails with the reference's "Invalid runtime encoding
- * encountered." (JEA_ERR_RANGE), as do entries the tables have no code for.  h_bits needs
+ * Encode: the DC difference and then every (run, value) entry as given, the run taken modulo 256 as the
+ * reference narrows it (entropy_encoder.cpp:733); (0, 0) is the end-of-block code, (15, 0) the zero-run code,
+ * another entry with value 0 fails with the reference's "Invalid runtime encoding encountered."
+ * (JEA_ERR_RANGE), as do entries the tables have no code for (the reference indexes past its tables there).  h_bits needs
  * (22 + 26 * n_entries + 31) / 32 words; bits are MSB first in each word, zero padded.
- * Decode: from the stream given to jea_stream_upload, starting at start_bit; at most 64 entries. */
+ * Decode: from the stream given to jea_stream_upload, starting at start_bit; entries until one is the end of
+ * block or the positions they cover add up to exactly 63 (:707-710).  A damaged stream whose count steps over
+ * 63 keeps the reference reading; here the call fails (JEA_ERR_BAD_STREAM) once 64 entries are out. */
 int jea_huffman_encode_rle(jea_ctx* ctx, int16_t dc_difference, const uint16_t* h_runs, const int16_t* h_values,
                            size_t n_entries, int is_luminance, uint32_t* length_bits, uint32_t* h_bits,
                            size_t bits_capacity_words);

@@ -16,7 +16,7 @@ EXPORTS = [
     "jea_set_profiling", "jea_last_phase_ms", "jea_set_scratch_budget", "jea_set_huffman_optimised",
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header", "jea_read_header_ex",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
-    "jea_encode_batch_static_async", "jea_static_scratch_needed",
+    "jea_encode_batch_static_async", "jea_static_scratch_needed", "jea_static_scratch_bytes",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
     "jea_decode_batch", "jea_decode_host",
     "jea_fdct_quant", "jea_fdct_quant_async", "jea_fdct_quant_planar_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_remove_stuffing", "jea_idct_dequant",
@@ -77,6 +77,8 @@ def load_library():
     lib.jea_encode_batch_static_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
     lib.jea_static_scratch_needed.argtypes = [sz, u16, u16]
     lib.jea_static_scratch_needed.restype = sz
+    lib.jea_static_scratch_bytes.argtypes = []
+    lib.jea_static_scratch_bytes.restype = sz
     lib.jea_stripe_transform.argtypes = [vp, vp, u16, u16, vp, vp, vp]
     lib.jea_stripe_bits.argtypes = [vp, vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint32)]
     lib.jea_stripe_finish.argtypes = [vp, c.c_uint64, i32, i32, c.c_uint32, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
@@ -165,7 +167,9 @@ def read_header_ex(jpeg):
     return w.value, h.value, lum, chrom, bool(own.value)
 
 
-STATIC_SCRATCH_BYTES = 48 << 20
+def static_scratch_bytes():
+    """Size of the library's built-in scratch buffer (JEA_STATIC_SCRATCH_BYTES), read from the loaded library."""
+    return load_library().jea_static_scratch_bytes()
 
 
 def static_scratch_needed(n_images, w, h):

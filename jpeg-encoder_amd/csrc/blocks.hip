@@ -148,9 +148,10 @@ __global__ __launch_bounds__(64) void huffman_decode_block_kernel(const uint8_t*
 // HuffmanEncoder::applyFinalEncoding (entropy_encoder.cpp:696-701, 715-765) for one block-channel whose
 // run-length form the caller supplies: the DC difference, then every (run, value) entry exactly as given --
 // (0, 0) is the end-of-block code, (15, 0) the zero-run code, any other entry with value 0 is the
-// reference's "Invalid runtime encoding encountered." (:748).  Entries the tables have no code for (a run
-// above 15, an amplitude of more than 10 bits, a DC difference of more than 11) index past the reference's
-// tables; here they are reported as the same error.  bits[] receives the MSB-first string, zero padded.
+// reference's "Invalid runtime encoding encountered." (:748).  The run is narrowed to 8 bits first, as the
+// reference does (:733: a run of 256 with value 0 is an end of block).  Entries the tables have no code for (a
+// narrowed run above 15 with a value, an amplitude of more than 10 bits, a DC difference of more than 11) index
+// past the reference's tables, which is undefined there; here they are reported as the same error.  bits[] receives the MSB-first string, zero padded.
 __global__ __launch_bounds__(64) void huffman_encode_rle_kernel(int dc_difference, const uint16_t* __restrict__ runs,
                                                                 const int16_t* __restrict__ values, uint32_t n,
                                                                 int is_lum, const HuffTables* __restrict__ huff,
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(64) void huffman_encode_rle_kernel(int dc_differenc
         sink.put(((e & 0xffffu) << s) | extra, (e >> 16) + s);
     }
     for (uint32_t i = 0; i < n && ok; ++i) {
-        const uint32_t run = runs[i];
+        const uint32_t run = runs[i] & 0xffu;   // uint8_t runLengthRRRR = acCoeff.m_runLength (:733)
         const int v = values[i];
         const uint32_t amp = (uint32_t)(v < 0 ? -v : v) & 0xffffu;
         const uint32_t s = bit_width(amp);
@@ -247,8 +248,10 @@ __global__ __launch_bounds__(64) void huffman_decode_rle_kernel(const uint8_t* _
         values[n] = (int16_t)val;
         ++n;
         processed += 1 + run;
-        if (processed > 63) { err = JEA_ERR_BAD_STREAM; break; }
+        // :707-710 goes on until the count is exactly 63 or an end-of-block entry comes; a count that steps over 63
+        // keeps the reference reading entries without bound, which this kernel ends at the 64 entries its output holds
         if ((run == 0 && val == 0) || processed == 63) break;
+        if (n == 64) { err = JEA_ERR_BAD_STREAM; break; }
     }
     if (rd.past_end()) err = JEA_ERR_BAD_STREAM;
     if (err) atomicExch(status, err);

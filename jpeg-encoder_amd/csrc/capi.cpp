@@ -38,6 +38,10 @@ thread_local std::string g_create_error;
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[kMaxDevices] = {};
+// Recorded behind every call that uses a GPU's copy and waited for by the next one, whichever context or
+// stream that comes from: users of the one buffer run one after the other.  Created with the address, kept
+// until the process ends.
+hipEvent_t g_scratch_free[kMaxDevices] = {};
 
 // Address of `scratch` on the current device (which must be `device`); asked for once per device.
 hipError_t static_scratch_of(int device, unsigned char** out) {
@@ -46,8 +50,9 @@ hipError_t static_scratch_of(int device, unsigned char** out) {
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
         void* p = nullptr;
-        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&g_scratch_free[device], hipEventDisableTiming)) != hipSuccess) return e;
         g_scratch_ptr[device] = (unsigned char*)p;
     }
     *out = g_scratch_ptr[device];
@@ -1110,9 +1115,28 @@ int jea_encode_batch_static_async(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_i
     sc.img_ff = sc.img_ubase + n_images;
     sc.tile_ff8 = (uint32_t*)(base + l.tile_ff8);
     // tile_ff and unstuffed stay null: only the stripe kernels use them
-    return enqueue_encode(ctx, d_rgb, n_images, width, height, lum_q, chr_q, (int16_t*)(base + l.coefs),
-                          base + l.masks, sc, d_out, out_capacity, d_offsets, d_sizes, d_status);
+    // Every context and stream of this GPU shares the buffer: this call's kernels start after those of the call
+    // that used it last (an event wait, no allocation, no host wait), and the pair wait / record is taken under a
+    // lock so that two host threads cannot both wait for the same predecessor.  A stream under graph capture is
+    // left alone: an event recorded into a capture cannot order work outside it, so there the graph's owner
+    // keeps its launches apart.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        capture = hipStreamCaptureStatusNone;
+    }
+    if (capture != hipStreamCaptureStatusNone)
+        return enqueue_encode(ctx, d_rgb, n_images, width, height, lum_q, chr_q, (int16_t*)(base + l.coefs),
+                              base + l.masks, sc, d_out, out_capacity, d_offsets, d_sizes, d_status);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    JEA_HIP(ctx, hipStreamWaitEvent(ctx->stream, g_scratch_free[ctx->device], 0));
+    const int rc = enqueue_encode(ctx, d_rgb, n_images, width, height, lum_q, chr_q, (int16_t*)(base + l.coefs),
+                                  base + l.masks, sc, d_out, out_capacity, d_offsets, d_sizes, d_status);
+    JEA_HIP(ctx, hipEventRecord(g_scratch_free[ctx->device], ctx->stream));
+    return rc;
 }
+
+size_t jea_static_scratch_bytes(void) { return kStaticScratchBytes; }
 
 int jea_encode_batch(jea_ctx* ctx, const uint8_t* d_rgb, size_t n_images, uint16_t width, uint16_t height,
                      const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* d_out, size_t out_capacity,
@@ -1381,7 +1405,9 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     if (ctx->profiling) ctx->n_marks = 5;   // unstuffing | synchronisation rounds | scan and write pass | follow-up
     if (with_headers && (rc = headers_ok())) return rc;
     if (report->unsettled != 0) {
+        // what produces the result from here on is not the pass whose phases were marked: no phase times for this call
         sc.marks = nullptr;
+        ctx->n_marks = 0;
         JEA_HIP(ctx, launch_entropy_decode(ctx->stream, d_data, d_seg, d_seg + n_images, plan, sc, step_tables, d_coefs,
                                            ctx->d_status, follow_up, report, prologue, false));
         JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -747,9 +747,14 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
         own_bits = tile_bits[t];
         const uint4 own_ff8 = tile_ff8[t];
         my_len = has_block ? len16[(size_t)img * nbc + b] : 0u;
-        if (status_now != 0) return;
+        // An error ends the workgroup -- all of it or none of it.  The status word may be raised while this kernel
+        // runs (by a neighbouring piece of a batch that is encoded on two streams), so the waves of a workgroup can
+        // read different values; each leaves what it saw in LDS, the scan's barriers lie between that store and the
+        // reads, and every wave then takes the same decision.
+        if ((threadIdx.x & 63u) == 0) psum[threadIdx.x >> 6] = (uint32_t)status_now;
         uint32_t tile_total;
         local_off = block_exclusive_scan_256(my_len, wsum, tile_total);
+        if ((psum[0] | psum[1] | psum[2] | psum[3]) != 0u) return;
         own_ff = ff_at(own_ff8, (uint32_t)base_bits);
     }
     const uint64_t end_bits = base_bits + own_bits;

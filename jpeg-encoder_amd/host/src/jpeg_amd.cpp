@@ -547,8 +547,9 @@ void HuffmanEncoder::applyFinalEncoding(RunLengthEncodedBlockChannelData const& 
     std::vector<uint16_t> runs(n);
     std::vector<int16_t> values(n);
     for (size_t i = 0; i < n; ++i) {
-        // a run that does not fit the interface is no valid run either way (the reference narrows it to 8 bits, :733)
-        runs[i] = static_cast<uint16_t>(std::min<size_t>(input.m_acCoefficients[i].m_runLength, 0xffff));
+        // the reference narrows the run to 8 bits before it looks at it (entropy_encoder.cpp:733): a run of 256 with
+        // value 0 is an end-of-block entry there, and so it is here
+        runs[i] = static_cast<uint16_t>(input.m_acCoefficients[i].m_runLength & 0xff);
         values[i] = input.m_acCoefficients[i].m_value;
     }
     std::vector<uint32_t> bits((22 + 26 * n + 31) / 32);

@@ -268,6 +268,23 @@ int main(int argc, char** argv) {
         jpeg::JPEGImage c;
         broken.encode(bmp, c);
         std::printf("bad_entries_done\n");
+        // the reference narrows an entry's run to 8 bits before it looks at it (entropy_encoder.cpp:733): a run of 256
+        // with value 0 is the end-of-block entry, and a file written with such entries is the baseline's file
+        class WideRuns final : public jpeg::HuffmanEncoder {
+        protected:
+            void applyFinalEncoding(jpeg::RunLengthEncodedBlockChannelData const& in, jpeg::BitStream& out, bool lum) const override {
+                jpeg::RunLengthEncodedBlockChannelData wide = in;
+                for (auto& e : wide.m_acCoefficients)
+                    if (e.m_value == 0 && e.m_runLength == 0) e.m_runLength = 256;
+                HuffmanEncoder::applyFinalEncoding(wide, out, lum);
+            }
+        };
+        WithCounting widened(std::make_unique<WideRuns>());
+        jpeg::JPEGImage d;
+        widened.encode(bmp, d);
+        const bool sameWide = d.m_compressedImageData.getSize() == b.m_compressedImageData.getSize() &&
+                              std::memcmp(d.m_compressedImageData.getDataPtr(), b.m_compressedImageData.getDataPtr(), d.m_compressedImageData.getSize()) == 0;
+        std::printf("wide_runs_narrowed encode_matches %d\n", int(sameWide));
     }
     {   // the injected coder with per-image tables: a smaller file that decodes to the same pixels; mixed with a
         // user's component it cannot work (two passes do not fit the per-block loop) and says so

@@ -1,0 +1,39 @@
+"""bench.py starts its own ranks: `--gpus 2` outside a launcher's environment must run two processes that find each
+other, and the line must say so.  The ranks share GPU 0 here and talk over gloo (JEA_DIST_BACKEND); on a node with
+a GPU per rank the same code runs over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, **env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_runs_two_ranks_of_the_stripe_protocol():
+    line = _bench("--gpus", "2", "--config", "c4", "--c4-size", "1024", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                  JEA_DIST_BACKEND="gloo")
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["comm_backend"] == "gloo"
+    assert line["config"]["file_checked_against"] == "oracle, byte for byte"
+    assert line["value"] > 0 and line["config"]["stripe_rows"] == 512
+
+
+def test_bench_gpus_2_shards_a_batch_by_image():
+    line = _bench("--gpus", "2", "--config", "c3", "--frames", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                  JEA_DIST_BACKEND="gloo")
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["config"]["workload"].startswith("batch of 6 1920x1080 frames") and "3 per rank" in line["config"]["workload"]

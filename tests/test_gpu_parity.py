@@ -775,6 +775,19 @@ def test_encode_batch_in_pieces_on_two_streams(jea, po):
                 with pytest.raises(b.JeaError) as e:
                     c.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=short, d_out=out[:short])
                 assert e.value.code == 3
+            if n == 260:
+                # a capacity that a middle piece exceeds (image 100 is in the second of five pieces): the status is
+                # raised while the pieces behind it are in flight on both streams; the call reports it and nothing
+                # is written past the capacity
+                short = int(off[100]) + 5
+                out.fill_(0xA5)
+                with pytest.raises(b.JeaError) as e:
+                    c.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=short, d_out=out[:short])
+                assert e.value.code == 3
+                assert bool((out[short:] == 0xA5).all())
+                # and the context is fine afterwards
+                _, off2, size2 = c.encode_batch(d_rgb, n, w, h, lum, chrom, capacity=cap, d_out=out)
+                assert np.array_equal(off2, off) and np.array_equal(size2, size)
     finally:
         c.close()
 
@@ -819,3 +832,56 @@ def test_contexts_on_two_gpus_from_one_thread(jea, po):
     finally:
         c0.close()
         c1.close()
+
+
+def test_two_stream_batches_on_three_contexts_at_once(jea, po):
+    """Three contexts, each driven by a host thread of its own, each encoding batches large enough to run as pieces on
+    two streams of the context: six streams that wait for one another's events, on a process with four hardware
+    queues.  Every wait is for an event recorded earlier on the host, all streams have the same priority, so the
+    queues cannot wait in a circle; the files are those of the oracle."""
+    import threading
+
+    import torch
+
+    b = jea.binding
+    w, h, quality = 72, 40, 85
+    lum, chrom = b.quant_tables(quality)
+    distinct = [po.gen_image(w, h, i % 3 if i % 3 < 2 else 0, 4100 + i) for i in range(7)]
+    want = [po.encode(im, quality) for im in distinct]
+    ctxs = [jea.Context(0) for _ in range(3)]
+    jobs = []
+    for t, c in enumerate(ctxs):
+        n = 131 + 64 * t
+        src = [(3 * i + t + i // 5) % 7 for i in range(n)]
+        jobs.append(dict(n=n, src=src, rgb=c.to_device(np.stack([distinct[k] for k in src]).reshape(-1)),
+                         cap=sum(len(want[k]) + 64 for k in src)))
+    torch.cuda.synchronize()
+    results, errors = [None] * 3, []
+
+    def work(t):
+        try:
+            j = jobs[t]
+            for _ in range(3):
+                out = torch.full((j["cap"],), 0xA5, dtype=torch.uint8, device=ctxs[t].tdev)
+                results[t] = (out,) + tuple(ctxs[t].encode_batch(j["rgb"], j["n"], w, h, lum, chrom, capacity=j["cap"], d_out=out)[1:])
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=100)
+    try:
+        assert not errors, errors
+        assert all(not th.is_alive() for th in threads)
+        for t in range(3):
+            out, off, size = results[t]
+            host, at = out.cpu().numpy(), 0
+            for i, k in enumerate(jobs[t]["src"]):
+                assert int(off[i]) == at and int(size[i]) == len(want[k]), (t, i)
+                assert host[at: at + len(want[k])].tobytes() == want[k], (t, i)
+                at = (at + len(want[k]) + 63) // 64 * 64
+    finally:
+        for c in ctxs:
+            c.close()

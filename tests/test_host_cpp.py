@@ -63,6 +63,8 @@ def test_baseline_encoder_cpp_on_gpu(tmp_path):
     # a user's entropy coder that overrides the protected final-encoding step of the reference's interface
     assert "user_entropy_coder encode_matches 1 decode_matches 1 encoded %d decoded %d" % (3 * 4 * 3, 3 * 4 * 3) in lines, r.stdout
     assert "[Error]: Invalid runtime encoding encountered." in lines and "bad_entries_done" in lines
+    # runs are narrowed to 8 bits as the reference narrows them (entropy_encoder.cpp:733): (256, 0) is an end of block
+    assert "wide_runs_narrowed encode_matches 1" in lines, r.stdout
     # the injected coder with per-image tables against the oracle's statement of the procedure
     t = next(ln.split() for ln in lines if ln.startswith("tailored_tables bytes"))
     want = po.encode_optimised(po.gen_image(160, 96, 0, 12), 60)
