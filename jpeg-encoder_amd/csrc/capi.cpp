@@ -1285,43 +1285,59 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
                               uint32_t* d_block_records = nullptr, const DecodeFollowUp& follow_up = nullptr) {
     int rc;
     const bool with_headers = skip == JEA_HEADER_BYTES;
-    const size_t seg_bytes = 3 * n_images * sizeof(uint64_t);   // offsets | sizes | unstuffed bases
-    const size_t hdr_bytes = with_headers ? n_images * JEA_HEADER_BYTES : 0;
-    if ((rc = ensure_pinned(ctx, 64 + seg_bytes + hdr_bytes))) return rc;
-    DecodeReport* report = (DecodeReport*)ctx->pinned;
-    uint64_t* seg = (uint64_t*)((uint8_t*)ctx->pinned + 64);
-    uint8_t* hdr = (uint8_t*)ctx->pinned + 64 + seg_bytes;
-    uint64_t max_size = 0, ubytes = 0, total_size = 0;
+    uint64_t max_size = 0, total_size = 0;
     bool too_short = false;   // reported after the headers have been looked at, as the reference would
+    std::vector<uint64_t> scan_sizes(n_images);
     for (size_t i = 0; i < n_images; ++i) {
         if (h_sizes[i] < skip) return fail(ctx, JEA_ERR_BAD_HEADER, "Failed to find SOI marker");
         if (h_sizes[i] < skip + 2) too_short = true;
-        seg[i] = h_offsets[i] + skip;
-        seg[n_images + i] = h_sizes[i] - skip;
-        seg[2 * n_images + i] = ubytes;
-        ubytes += (h_sizes[i] - skip + 15) / 16 * 16 + 16;
-        if (h_sizes[i] - skip > max_size) max_size = h_sizes[i] - skip;
-        total_size += h_sizes[i] - skip;
+        scan_sizes[i] = h_sizes[i] - skip;
+        if (scan_sizes[i] > max_size) max_size = scan_sizes[i];
+        total_size += scan_sizes[i];
     }
     if (mcus * 3 > 0x7fffffffull || max_size > (1ull << 34))
         return fail(ctx, JEA_ERR_INVALID_ARG, "decode: image or stream too large");
-    const DecodePlan plan = plan_entropy_decode(n_images, max_size, mcus, total_size);
-    const size_t subs = plan.subs_per_image;
-    if ((rc = ensure(ctx, ctx->seg_offsets, seg_bytes))) return rc;
+    // Every image gets the workgroups its own scan needs; with many images the kernels look their image up in a
+    // table, which travels with the scan ranges.
+    const DecodePlan plan = plan_entropy_decode(n_images, scan_sizes.data(), max_size, mcus, total_size);
+    if ((uint64_t)plan.total_groups * 240ull > 0x7fffffffull)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "decode: streams too large for one call");
+    // host to device: offsets | sizes | unstuffed bases | first workgroup of every image | (image, group) per workgroup
+    const size_t seg_bytes = 3 * n_images * sizeof(uint64_t);
+    const size_t first_bytes = plan.mapped ? (n_images * sizeof(uint32_t) + 7) / 8 * 8 : 0;
+    const size_t map_bytes = plan.mapped ? (size_t)plan.total_groups * 2 * sizeof(uint32_t) : 0;
+    const size_t up_bytes = seg_bytes + first_bytes + map_bytes;
+    const size_t hdr_bytes = with_headers ? n_images * JEA_HEADER_BYTES : 0;
+    if ((rc = ensure_pinned(ctx, 64 + up_bytes + hdr_bytes))) return rc;
+    DecodeReport* report = (DecodeReport*)ctx->pinned;
+    uint64_t* seg = (uint64_t*)((uint8_t*)ctx->pinned + 64);
+    uint8_t* hdr = (uint8_t*)ctx->pinned + 64 + up_bytes;
+    uint64_t ubytes = 0;
+    for (size_t i = 0; i < n_images; ++i) {
+        seg[i] = h_offsets[i] + skip;
+        seg[n_images + i] = scan_sizes[i];
+        seg[2 * n_images + i] = ubytes;
+        ubytes += (scan_sizes[i] + 15) / 16 * 16 + 16;
+    }
+    if (plan.mapped)
+        fill_group_map(plan, scan_sizes.data(), (uint32_t*)((uint8_t*)seg + seg_bytes),
+                       (uint32_t*)((uint8_t*)seg + seg_bytes + first_bytes));
+    const size_t subs = plan.total_subs, groups = plan.total_groups;
+    if ((rc = ensure(ctx, ctx->seg_offsets, up_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->ustream, ubytes))) return rc;
     if ((rc = ensure(ctx, ctx->chunk_drops, n_images * plan.n_chunks * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->chunk_base, n_images * plan.n_chunks * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->img_drops, n_images * sizeof(uint64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->sub_end, n_images * subs * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->sub_used, n_images * subs * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->sub_info, n_images * subs * sizeof(int4)))) return rc;
-    if ((rc = ensure(ctx, ctx->grp_sum, n_images * plan.n_groups * sizeof(int4)))) return rc;
-    if ((rc = ensure(ctx, ctx->grp_base, n_images * plan.n_groups * sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_end, subs * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_used, subs * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_info, subs * sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->grp_sum, groups * sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->grp_base, groups * sizeof(int4)))) return rc;
     if ((rc = ensure(ctx, ctx->round_flags, 4 * sizeof(uint32_t)))) return rc;
     constexpr uint32_t kContextSlots = 1u << 18;
-    if ((rc = ensure(ctx, ctx->grp_pending, n_images * plan.n_groups * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->grp_end, n_images * plan.n_groups * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->sub_guess, n_images * subs * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->grp_pending, groups * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->grp_end, groups * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sub_guess, subs * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->first_bad, n_images * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ctx_keys, kContextSlots * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->ctx_vals, kContextSlots * sizeof(uint32_t)))) return rc;
@@ -1336,7 +1352,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
         prologue.h_words = seg;
         prologue.n_words = (uint32_t)(3 * n_images);
     } else {
-        JEA_HIP(ctx, hipMemcpyAsync(ctx->seg_offsets.ptr, seg, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
+        JEA_HIP(ctx, hipMemcpyAsync(ctx->seg_offsets.ptr, seg, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     const uint64_t* d_seg = (const uint64_t*)ctx->seg_offsets.ptr;
     auto headers_ok = [&]() -> int {
@@ -1365,6 +1381,10 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     }
     DecodeScratch sc;
     sc.ubase = d_seg + 2 * n_images;
+    if (plan.mapped) {
+        sc.img_first = (const uint32_t*)((const uint8_t*)ctx->seg_offsets.ptr + seg_bytes);
+        sc.grp_map = (const uint32_t*)((const uint8_t*)ctx->seg_offsets.ptr + seg_bytes + first_bytes);
+    }
     sc.ustream = (uint8_t*)ctx->ustream.ptr;
     sc.chunk_drops = (uint32_t*)ctx->chunk_drops.ptr;
     sc.chunk_base = (uint64_t*)ctx->chunk_base.ptr;
@@ -1423,7 +1443,7 @@ int jea_remove_stuffing(jea_ctx* ctx, const uint8_t* d_scan, size_t len, uint8_t
     if (!d_scan || !d_out || !out_len || len == 0 || len > ((size_t)1 << 34))
         return fail(ctx, JEA_ERR_INVALID_ARG, "jea_remove_stuffing: invalid argument");
     JEA_HIP(ctx, hipSetDevice(ctx->device));
-    const DecodePlan plan = plan_entropy_decode(1, len, 1);
+    const DecodePlan plan = plan_entropy_decode(1, nullptr, len, 1);
     int rc;
     if ((rc = ensure(ctx, ctx->seg_offsets, 3 * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ustream, (len + 15) / 16 * 16 + 16))) return rc;

@@ -64,6 +64,40 @@ constexpr uint32_t kSubWordsSmall = 2, kSubWordsMedium = 4, kSubWordsLarge = 16;
 constexpr uint32_t kWarm = 16;
 constexpr uint32_t kOwned = kThreads - kWarm;
 
+// Which image a workgroup belongs to and which of that image's groups it is.  A job's workgroups are numbered
+// through, image after image, each image having groups_of_scan(its raw scan bytes) of them; `first` is the number
+// of the image's group 0.  Everything kept per group or per sub-sequence is indexed by the running number.
+struct GroupMap {
+    const uint2* map;            // jobs of more than kPlanScanImages images: (image, group) of every workgroup, from the host
+    const uint32_t* img_first;   // ... and every image's first workgroup
+    uint32_t n_images;
+};
+struct GroupId {
+    uint32_t img, group, first;
+};
+// size_of(i): raw scan bytes of image i (from device memory, or from the kernel's arguments)
+template <class SizeOf>
+__device__ __forceinline__ GroupId locate_group(const GroupMap& gm, uint32_t wg, uint32_t group_raw, SizeOf size_of) {
+    if (gm.map != nullptr) {
+        const uint2 e = gm.map[wg];
+        return GroupId{e.x, e.y, wg - e.y};
+    }
+    uint32_t first = 0, img = 0;
+    for (; img + 1 < gm.n_images; ++img) {   // a few images at most: wave-uniform scalar work
+        const uint32_t g = groups_of_scan(size_of(img), group_raw);
+        if (wg < first + g) break;
+        first += g;
+    }
+    return GroupId{img, wg - first, first};
+}
+template <class SizeOf>
+__device__ __forceinline__ uint32_t first_group_of(const GroupMap& gm, uint32_t img, uint32_t group_raw, SizeOf size_of) {
+    if (gm.img_first != nullptr) return gm.img_first[img];
+    uint32_t first = 0;
+    for (uint32_t i = 0; i < img; ++i) first += groups_of_scan(size_of(i), group_raw);
+    return first;
+}
+
 // state word: bits 0-7 bit offset past the sub-sequence start, 8-9 channel, 16-21 zig-zag progress
 __device__ __forceinline__ uint32_t make_state(uint32_t ovf, uint32_t c, uint32_t z) { return ovf | (c << 8) | (z << 16); }
 
@@ -779,7 +813,7 @@ constexpr uint32_t kMaxLocalIterations = 16;   // repair steps per launch; what 
 struct RawSource {
     const uint8_t* scan = nullptr;       // all files; image i's scan starts at offsets[i] and is sizes[i] raw bytes long
     const uint64_t* offsets = nullptr;
-    uint32_t* grp_end = nullptr;         // [n][n_groups] end state of each group's last sub-sequence
+    uint32_t* grp_end = nullptr;         // [groups] end state of each group's last sub-sequence
 };
 // Jobs the first kernel of the chain does on the side (see unstuff_count_kernel, which does them when there is
 // an unstuffing pass): clearing *status and *check_flag, scan ranges from kernel arguments, header gather.
@@ -800,7 +834,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
                                                                const uint64_t* __restrict__ ubase,
                                                                const uint64_t* __restrict__ sizes,
                                                                const uint64_t* __restrict__ img_drops,
-                                                               uint32_t n_groups, int first_round,
+                                                               GroupMap gm, int first_round,
                                                                const StepTables* __restrict__ tables,
                                                                uint32_t* __restrict__ sub_end,
                                                                uint32_t* __restrict__ sub_used,
@@ -820,20 +854,24 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
     __shared__ Sums red[4];
     __shared__ uint32_t scratch[8];
 
-    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
-    const size_t group_index = (size_t)img * n_groups + group;
+    const uint32_t tid = threadIdx.x;
+    const bool from_args = kRaw && first_round && pro.n_words != 0;   // the scan ranges are kernel arguments
+    const GroupId gid = from_args ? locate_group(gm, blockIdx.x, kGroupRaw, [&](uint32_t i) { return pro.words.v[gm.n_images + i]; })
+                                  : locate_group(gm, blockIdx.x, kGroupRaw, [&](uint32_t i) { return sizes[i]; });
+    const uint32_t group = gid.group, img = gid.img;
+    const size_t group_index = blockIdx.x;
     uint64_t raw_len = 0, raw_offset = 0, ulen = 0, total_bits = 0;
     bool empty;
     if (kRaw) {
         if (first_round) {
-            if (group == 0 && img == 0 && tid == 0) {
+            if (blockIdx.x == 0 && tid == 0) {
                 *pro.status = 0;
                 *pro.check_flag = 0;
             }
-            if (group == 0 && img == 0 && tid < pro.n_words) pro.d_words[tid] = pro.words.v[tid];
+            if (blockIdx.x == 0 && tid < pro.n_words) pro.d_words[tid] = pro.words.v[tid];
         }
-        raw_offset = (first_round && pro.n_words) ? pro.words.v[img] : raw.offsets[img];
-        raw_len = (first_round && pro.n_words) ? pro.words.v[gridDim.y + img] : sizes[img];
+        raw_offset = from_args ? pro.words.v[img] : raw.offsets[img];
+        raw_len = from_args ? pro.words.v[gm.n_images + img] : sizes[img];
         if (first_round && pro.headers_out != nullptr && group == 0) {
             const uint8_t* src = raw.scan + raw_offset - pro.header_bytes;
             for (uint32_t i = tid; i < pro.header_bytes; i += kThreads) pro.headers_out[(size_t)img * pro.header_bytes + i] = src[i];
@@ -910,7 +948,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         if (tid == 0) ends[0] = 0;
     }
 
-    load_tables(t, tables + (tables_per_image ? blockIdx.y : 0u));
+    load_tables(t, tables + (tables_per_image ? img : 0u));
     uint32_t limit = 0xffffffffu, n_active = kOwned;
     if (kRaw) {
         const RawGroup rg = stage_group_raw(gw, raw.scan + raw_offset, raw_len, (uint64_t)group * kGroupRaw,
@@ -994,16 +1032,18 @@ constexpr uint32_t kContextWords = 16;   // stream words before a sub-sequence t
 template <uint32_t W>
 __global__ __launch_bounds__(kThreads) void first_unproven_kernel(const uint64_t* __restrict__ sizes,
                                                                   const uint64_t* __restrict__ img_drops,
-                                                                  uint32_t n_groups,
+                                                                  GroupMap gm,
                                                                   const uint32_t* __restrict__ sub_end,
                                                                   const uint32_t* __restrict__ sub_used,
                                                                   uint32_t* __restrict__ first_bad) {
-    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const GroupId gid = locate_group(gm, blockIdx.x, kOwned * 4 * W, [&](uint32_t i) { return sizes[i]; });
+    const uint32_t group = gid.group, img = gid.img;
     if (tid >= kOwned) return;
     const uint64_t total_bits = 8 * (sizes[img] - img_drops[img]);
     const uint64_t sub = (uint64_t)group * kOwned + tid;
     if (sub * 32 * W >= total_bits) return;
-    const size_t sub_index = (size_t)img * n_groups * kOwned + sub;
+    const size_t sub_index = (size_t)blockIdx.x * kOwned + tid;
     const uint32_t before = sub == 0 ? 0u : sub_end[sub_index - 1];
     if (sub_used[sub_index] != before) atomicMin(&first_bad[img], (uint32_t)sub);
 }
@@ -1028,18 +1068,20 @@ __global__ __launch_bounds__(kThreads) void context_kernel(const uint8_t* __rest
                                                            const uint64_t* __restrict__ ubase,
                                                            const uint64_t* __restrict__ sizes,
                                                            const uint64_t* __restrict__ img_drops,
-                                                           uint32_t n_groups, const uint32_t* __restrict__ first_bad,
+                                                           GroupMap gm, const uint32_t* __restrict__ first_bad,
                                                            const uint32_t* __restrict__ sub_used,
                                                            unsigned long long* __restrict__ keys,
                                                            uint32_t* __restrict__ vals, uint32_t table_mask,
                                                            uint32_t* __restrict__ sub_guess) {
-    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const GroupId gid = locate_group(gm, blockIdx.x, kOwned * 4 * W, [&](uint32_t i) { return sizes[i]; });
+    const uint32_t group = gid.group, img = gid.img;
     if (tid >= kOwned) return;
     const uint64_t sub = (uint64_t)group * kOwned + tid;
     const bool proven = sub < first_bad[img];
     if (kLearn != proven) return;
     const uint64_t ulen = sizes[img] - img_drops[img];
-    const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + tid;
+    const size_t sub_index = (size_t)blockIdx.x * kOwned + tid;
     const uint64_t first_word = sub * W;
     const bool usable = first_word >= kContextWords && (first_word + 1) * 4 <= ulen;
     if (!kLearn) sub_guess[sub_index] = kNoState;
@@ -1071,7 +1113,7 @@ __global__ __launch_bounds__(kThreads) void context_kernel(const uint8_t* __rest
 // With `unsettled` given it also does what one more synchronisation round would find out: whether
 // every workgroup's first sub-sequence was decoded from the end state of the sub-sequence before it
 // and no workgroup ran out of repair steps.  If so the fixed point is proven; if not the flag is set.
-__global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __restrict__ grp_sum, uint32_t n_groups,
+__global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __restrict__ grp_sum, GroupMap gm,
                                                                uint32_t total_blocks, int4* __restrict__ grp_base,
                                                                int32_t* __restrict__ status,
                                                                const uint64_t* __restrict__ sizes,
@@ -1084,6 +1126,10 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
     __shared__ Sums lds4[4];
     __shared__ Sums carry_s;
     const uint32_t img = blockIdx.x;
+    // this image's groups: n_groups of them from number `first` on
+    const uint32_t group_raw = kOwned * sub_bits / 8;
+    const size_t first = first_group_of(gm, img, group_raw, [&](uint32_t i) { return sizes[i]; });
+    const uint32_t n_groups = groups_of_scan(sizes[img], group_raw);
     if (threadIdx.x == 0) carry_s = Sums{0, 0, 0, 0};
     __syncthreads();
     // raw_grp_end given: the decoder that reads the raw scan -- a group is kOwned * sub_bits / 8 raw bytes, and the
@@ -1095,19 +1141,19 @@ __global__ __launch_bounds__(kThreads) void scan_groups_kernel(const int4* __res
         const uint32_t g = g0 + threadIdx.x;
         Sums v{0, 0, 0, 0};
         if (g < n_groups) {
-            const int4 s = grp_sum[(size_t)img * n_groups + g];
+            const int4 s = grp_sum[first + g];
             v = Sums{s.x, s.y, s.z, s.w};
             if (unsettled != nullptr && (uint64_t)g * kOwned * sub_bits < total_bits) {
-                const size_t first = ((size_t)img * n_groups + g) * kOwned;
+                const size_t first_sub = (first + g) * kOwned;
                 uint32_t entry = 0;   // the stream starts in state 0
-                if (g > 0) entry = raw ? raw_grp_end[(size_t)img * n_groups + g - 1] : sub_end[first - 1];
-                open_end = open_end || entry != sub_used[first] || grp_pending[(size_t)img * n_groups + g] != 0;
+                if (g > 0) entry = raw ? raw_grp_end[first + g - 1] : sub_end[first_sub - 1];
+                open_end = open_end || entry != sub_used[first_sub] || grp_pending[first + g] != 0;
             }
         }
         Sums total;
         const Sums excl = block_exclusive_scan(v, lds4, total);
         const Sums base = carry_s + excl;
-        if (g < n_groups) grp_base[(size_t)img * n_groups + g] = make_int4(base.nb, base.dc0, base.dc1, base.dc2);
+        if (g < n_groups) grp_base[first + g] = make_int4(base.nb, base.dc0, base.dc1, base.dc2);
         __syncthreads();
         if (threadIdx.x == 0) carry_s = carry_s + total;
         __syncthreads();
@@ -1128,7 +1174,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
                                                                 const uint64_t* __restrict__ ubase,
                                                                 const uint64_t* __restrict__ sizes,
                                                                 const uint64_t* __restrict__ img_drops,
-                                                                uint32_t n_groups, uint32_t total_blocks,
+                                                                GroupMap gm, uint32_t total_blocks,
                                                                 const StepTables* __restrict__ tables,
                                                                 const uint32_t* __restrict__ sub_used,
                                                                 const int4* __restrict__ sub_info,
@@ -1149,7 +1195,10 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     __shared__ __align__(8) uint32_t acc[kThreads * kAccWords];
     __shared__ uint32_t scratch[8];
 
-    const uint32_t group = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const GroupId gid = locate_group(gm, blockIdx.x, kGroupRaw, [&](uint32_t i) { return sizes[i]; });
+    const uint32_t group = gid.group, img = gid.img;
+    const size_t group_index = blockIdx.x, first_group = gid.first;
     // classic: lengths of the unstuffed stream; raw: raw_len is the scan's length in the file
     const uint64_t raw_len = sizes[img];
     const uint64_t ulen = kRaw ? 0 : raw_len - img_drops[img];
@@ -1164,7 +1213,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     if (kFold) {
         Sums before{0, 0, 0, 0};
         for (uint32_t g = tid; g < group; g += kThreads) {
-            const int4 v = grp_sum[(size_t)img * n_groups + g];
+            const int4 v = grp_sum[first_group + g];
             before = before + Sums{v.x, v.y, v.z, v.w};
         }
 #pragma unroll
@@ -1177,30 +1226,30 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
         __syncthreads();
         gb = make_int4(before.nb, before.dc0, before.dc1, before.dc2);
         if (tid == 0) {
-            const size_t first = ((size_t)img * n_groups + group) * kOwned;
+            const size_t first = group_index * kOwned;
             if (unsettled != nullptr) {
                 uint32_t entry = 0;   // the stream starts in state 0
-                if (group > 0) entry = kRaw ? raw.grp_end[(size_t)img * n_groups + group - 1] : sub_end[first - 1];
-                if (entry != sub_used[first] || grp_pending[(size_t)img * n_groups + group] != 0) atomicOr(unsettled, 1u);
+                if (group > 0) entry = kRaw ? raw.grp_end[group_index - 1] : sub_end[first - 1];
+                if (entry != sub_used[first] || grp_pending[group_index] != 0) atomicOr(unsettled, 1u);
             }
             // the workgroup that holds the end of the stream: fewer blocks than the picture needs is a stream
             // error (the serial decoder would run off the end of the file)
             if (holds_end) {
-                const int4 own = grp_sum[(size_t)img * n_groups + group];
+                const int4 own = grp_sum[group_index];
                 if ((uint32_t)(before.nb + own.x) < total_blocks) atomicCAS(status, 0, JEA_ERR_BAD_STREAM);
             }
         }
     } else {
-        gb = grp_base[(size_t)img * n_groups + group];
+        gb = grp_base[group_index];
     }
     if ((uint32_t)gb.x >= total_blocks) return;   // the picture is complete before this group
     // slot tid holds the group's tid-th sub-sequence; the last kWarm threads have none
-    const size_t sub_index = ((size_t)img * n_groups + group) * kOwned + tid;
+    const size_t sub_index = group_index * kOwned + tid;
 
     // asked for first, so that they are under way while tables and stream are staged
     const int4 si = tid < kOwned ? sub_info[sub_index] : make_int4(0, 0, 0, 0);
     const uint32_t start_state = tid < kOwned ? sub_used[sub_index] : 0u;
-    load_tables(t, tables + (tables_per_image ? blockIdx.y : 0u));
+    load_tables(t, tables + (tables_per_image ? img : 0u));
     const uint8_t* stream = kRaw ? nullptr : ustream + ubase[img];
     bool active;
     uint32_t limit = 0xffffffffu;
@@ -1455,7 +1504,10 @@ void launch_build_step_tables(hipStream_t s, const uint8_t* d_data, const uint64
     build_step_tables_kernel<<<(unsigned)n_images, kThreads, 0, s>>>(d_data, d_scan_offsets, header_bytes, 0u, d_tables);
 }
 
-DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image, size_t total_scan_bytes) {
+uint32_t decode_group_bytes(uint32_t sub_words) { return kOwned * 4u * sub_words; }
+
+DecodePlan plan_entropy_decode(size_t n_images, const uint64_t* scan_sizes, size_t max_scan_bytes, size_t mcus_per_image,
+                               size_t total_scan_bytes) {
     DecodePlan p;
     p.n_images = (uint32_t)n_images;
     p.n_chunks = (uint32_t)((max_scan_bytes + kChunkBytes - 1) / kChunkBytes);
@@ -1463,17 +1515,24 @@ DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mc
     // the longest sub-sequences that still give the GPU a few workgroups per compute unit
     const uint32_t sizes[3] = {kSubWordsLarge, kSubWordsMedium, kSubWordsSmall};
     for (uint32_t w : sizes) {
-        const uint64_t subs = ((uint64_t)max_scan_bytes * 8 + 32 * w - 1) / (32 * w);
+        const uint32_t group_bytes = decode_group_bytes(w);
         p.sub_words = w;
-        p.n_groups = (uint32_t)((subs + kOwned - 1) / kOwned);
-        if (p.n_groups == 0) p.n_groups = 1;
+        p.n_groups = groups_of_scan(max_scan_bytes, group_bytes);
+        uint64_t total = 0;
+        if (scan_sizes != nullptr)
+            for (size_t i = 0; i < n_images; ++i) total += groups_of_scan(scan_sizes[i], group_bytes);
+        else
+            total = (uint64_t)p.n_groups * n_images;
+        p.total_groups = (uint32_t)total;
 #ifdef JEA_PLAN_MIN_GROUPS   // experiments: tools/build_variant.sh <name> -DJEA_PLAN_MIN_GROUPS=<n>
-        if ((uint64_t)p.n_groups * n_images >= JEA_PLAN_MIN_GROUPS) break;
+        if (total >= JEA_PLAN_MIN_GROUPS) break;
 #else
-        if ((uint64_t)p.n_groups * n_images >= 512) break;
+        if (total >= 512) break;
 #endif
     }
     p.subs_per_image = (size_t)p.n_groups * kOwned;
+    p.total_subs = (size_t)p.total_groups * kOwned;
+    p.mapped = n_images > kPlanScanImages;
     p.total_blocks = (uint32_t)(mcus_per_image * 3);
     // Block records four at a time (BlockWriter::put_record): where the launch has workgroups with work to spare, and
     // not for pictures full of detail, where a thread has few blocks.  Write pass, records singly / in fours:
@@ -1483,6 +1542,19 @@ DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mc
     const uint64_t busy_groups = total_scan_bytes / ((uint64_t)kOwned * 4 * p.sub_words);
     p.records_in_fours = busy_groups >= 256 && (uint64_t)total_scan_bytes * 8 < 40ull * p.total_blocks * n_images;
     return p;
+}
+
+void fill_group_map(const DecodePlan& plan, const uint64_t* scan_sizes, uint32_t* img_first, uint32_t* map) {
+    const uint32_t group_bytes = decode_group_bytes(plan.sub_words);
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < plan.n_images; ++i) {
+        const uint32_t n = scan_sizes != nullptr ? groups_of_scan(scan_sizes[i], group_bytes) : plan.n_groups;
+        img_first[i] = at;
+        for (uint32_t g = 0; g < n; ++g, ++at) {
+            map[2 * (size_t)at] = i;
+            map[2 * (size_t)at + 1] = g;
+        }
+    }
 }
 
 namespace {
@@ -1508,7 +1580,8 @@ struct DecodeRun {
     const DecodePrologue* prologue = nullptr;
     bool tables_per_image = false;   // d_tables is an array, one set per image (launch_build_step_tables)
 
-    dim3 grid() const { return dim3(p.n_groups, p.n_images); }
+    dim3 grid() const { return dim3(p.total_groups); }
+    GroupMap group_map() const { return GroupMap{reinterpret_cast<const uint2*>(sc.grp_map), sc.img_first, p.n_images}; }
     RawSource source() const { return raw ? RawSource{d_scan, d_offsets, sc.grp_end} : RawSource{}; }
     void sync_round(int first, uint32_t* flag, bool with_guesses) const {
         if (raw) {
@@ -1524,12 +1597,12 @@ struct DecodeRun {
                     rp.header_bytes = prologue->header_bytes;
                 }
             }
-            decode_sync_kernel<W, true><<<grid(), kThreads, 0, s>>>(nullptr, nullptr, d_sizes, nullptr, p.n_groups, first, d_tables,
+            decode_sync_kernel<W, true><<<grid(), kThreads, 0, s>>>(nullptr, nullptr, d_sizes, nullptr, group_map(), first, d_tables,
                                                                    sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
                                                                    sc.grp_pending, nullptr, nullptr, sc.mode.lum_mask, flag,
                                                                    source(), rp, tables_per_image ? 1u : 0u);
         } else {
-            decode_sync_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, first,
+            decode_sync_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, group_map(), first,
                                                                     d_tables, sc.sub_end, sc.sub_used, sc.sub_info, sc.grp_sum,
                                                                     sc.grp_pending, with_guesses ? sc.sub_guess : nullptr,
                                                                     sc.first_bad, sc.mode.lum_mask, flag, RawSource{}, RawPrologue{},
@@ -1539,7 +1612,7 @@ struct DecodeRun {
     template <bool kPlanar, bool kFold, bool kRaw, bool kFours>
     void write_launch(uint32_t* check) const {
         decode_write_kernel<W, kPlanar, kFold, kRaw, kFours><<<grid(), kThreads, 0, s>>>(
-            sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups, p.total_blocks, d_tables, sc.sub_used, sc.sub_info,
+            sc.ustream, sc.ubase, d_sizes, sc.img_drops, group_map(), p.total_blocks, d_tables, sc.sub_used, sc.sub_info,
             sc.grp_base, d_coefs, kPlanar ? sc.out_records : nullptr, sc.mode.lum_mask, d_status, sc.grp_sum, sc.sub_end,
             sc.grp_pending, check, source(), tables_per_image ? 1u : 0u);
     }
@@ -1553,7 +1626,7 @@ struct DecodeRun {
     void scan_and_write(uint32_t* check = nullptr) const {
         const bool fold = raw && p.n_groups <= kFoldGroups;
         if (!fold)
-            scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, p.n_groups, p.total_blocks, sc.grp_base,
+            scan_groups_kernel<<<p.n_images, kThreads, 0, s>>>(sc.grp_sum, group_map(), p.total_blocks, sc.grp_base,
                                                                d_status, d_sizes, sc.img_drops, 32 * W, sc.sub_end,
                                                                sc.sub_used, sc.grp_pending, check, raw ? sc.grp_end : nullptr);
         const bool planar = sc.out_records != nullptr;
@@ -1599,12 +1672,12 @@ struct DecodeRun {
             const bool guesses = extra < 64;
             if (guesses) {
                 if ((e = hipMemsetAsync(sc.first_bad, 0xff, p.n_images * sizeof(uint32_t), s)) != hipSuccess) return e;
-                first_unproven_kernel<W><<<grid(), kThreads, 0, s>>>(d_sizes, sc.img_drops, p.n_groups, sc.sub_end,
+                first_unproven_kernel<W><<<grid(), kThreads, 0, s>>>(d_sizes, sc.img_drops, group_map(), sc.sub_end,
                                                                     sc.sub_used, sc.first_bad);
-                context_kernel<W, true><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                context_kernel<W, true><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, group_map(),
                                                                    sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
                                                                    sc.ctx_slots - 1, sc.sub_guess);
-                context_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, p.n_groups,
+                context_kernel<W, false><<<grid(), kThreads, 0, s>>>(sc.ustream, sc.ubase, d_sizes, sc.img_drops, group_map(),
                                                                     sc.first_bad, sc.sub_used, sc.ctx_keys, sc.ctx_vals,
                                                                     sc.ctx_slots - 1, sc.sub_guess);
             }

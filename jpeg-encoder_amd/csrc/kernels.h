@@ -211,36 +211,58 @@ void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, 
 
 // Parallel Huffman decode (decode.hip).  The scan of image i is the byte range
 // [d_offsets[i], d_offsets[i] + d_sizes[i]) of d_scan and ends with the EOI marker.
+// The plan is ragged: every image gets the workgroups its own scan needs -- groups_of_scan(bytes) of them, each owning
+// a fixed range of raw scan bytes -- and the job's workgroups are numbered through, image after image.  Whatever
+// is kept per workgroup or per sub-sequence is indexed by that running number, so one file much longer than the
+// others costs its own workgroups and nothing else.
 struct DecodePlan {
     uint32_t n_images = 0;
     uint32_t n_chunks = 0;      // 4096-byte pieces of the longest raw scan
     uint32_t sub_words = 0;     // 32-bit words of unstuffed stream per sub-sequence (one thread's share)
     uint32_t n_groups = 0;      // workgroups covering the longest scan
-    size_t subs_per_image = 0;  // sub-sequence records per image
+    uint32_t total_groups = 0;  // workgroups of the whole job: the sum over the images
+    size_t subs_per_image = 0;  // sub-sequence records of the longest scan
+    size_t total_subs = 0;      // sub-sequence records of the whole job
     uint32_t total_blocks = 0;  // block-channels per image
     bool records_in_fours = false;   // the write pass stores block records as aligned 16-byte fours
+    // More than kPlanScanImages images: the kernels find a workgroup's image in a table made on the host
+    // (fill_group_map); up to that many they add up the images' workgroup counts themselves.
+    bool mapped = false;
 };
-// total_scan_bytes: of all images together; 0 = not known
-DecodePlan plan_entropy_decode(size_t n_images, size_t max_scan_bytes, size_t mcus_per_image, size_t total_scan_bytes = 0);
+constexpr uint32_t kPlanScanImages = 16;
+// Raw scan bytes that one workgroup owns, for sub-sequences of sub_words words, and workgroups of a scan.
+uint32_t decode_group_bytes(uint32_t sub_words);
+__host__ __device__ inline uint32_t groups_of_scan(uint64_t scan_bytes, uint32_t group_bytes) {
+    const uint64_t g = (scan_bytes + group_bytes - 1) / group_bytes;
+    return g ? (uint32_t)g : 1u;
+}
+// scan_sizes: raw scan bytes per image (null: every image max_scan_bytes long).
+DecodePlan plan_entropy_decode(size_t n_images, const uint64_t* scan_sizes, size_t max_scan_bytes, size_t mcus_per_image,
+                               size_t total_scan_bytes = 0);
+// For a mapped plan: img_first[i] = number of image i's first workgroup; map[2 g], map[2 g + 1] = image and
+// workgroup-within-the-image of workgroup g.  Images in the order given (the kernels do not care).
+void fill_group_map(const DecodePlan& plan, const uint64_t* scan_sizes, uint32_t* img_first, uint32_t* map);
 
-// Caller-provided scratch; n = images, subs = DecodePlan::subs_per_image.
+// Caller-provided scratch; n = images, subs = DecodePlan::total_subs, groups = DecodePlan::total_groups.
 struct DecodeScratch {
+    const uint32_t* grp_map = nullptr;     // mapped plans: device copies of what fill_group_map made
+    const uint32_t* img_first = nullptr;
     const uint64_t* ubase;   // [n] byte offset (multiple of 16) of image i's unstuffed stream in `ustream`;
                              //     streams need as many bytes as their raw scans, rounded up to 16
     uint8_t* ustream;
     uint32_t* chunk_drops;   // [n][n_chunks] stuffed zeros per raw chunk
     uint64_t* chunk_base;    // [n][n_chunks] exclusive scan
     uint64_t* img_drops;     // [n]
-    uint32_t* sub_end;       // [n][subs] decoder state at the end of each sub-sequence
-    uint32_t* sub_used;      // [n][subs] state the sub-sequence was last decoded from
-    int4* sub_info;          // [n][subs] blocks completed, DC-difference sums of Y, Cb, Cr
-    int4* grp_sum;           // [n][n_groups]
-    int4* grp_base;          // [n][n_groups] exclusive scan
+    uint32_t* sub_end;       // [subs] decoder state at the end of each sub-sequence
+    uint32_t* sub_used;      // [subs] state the sub-sequence was last decoded from
+    int4* sub_info;          // [subs] blocks completed, DC-difference sums of Y, Cb, Cr
+    int4* grp_sum;           // [groups]
+    int4* grp_base;          // [groups] exclusive scan within each image
     uint32_t* changed;       // [4] round flags
-    uint32_t* grp_pending;   // [n][n_groups] workgroup ran out of repair steps in the last round
-    uint32_t* grp_end;       // [n][n_groups] raw decoder: end state of the group's last sub-sequence
+    uint32_t* grp_pending;   // [groups] workgroup ran out of repair steps in the last round
+    uint32_t* grp_end;       // [groups] raw decoder: end state of the group's last sub-sequence
     bool tables_per_image = false;   // the StepTables pointer given to the launch functions is an array, one per image
-    uint32_t* sub_guess;     // [n][subs] start states offered from the stream context
+    uint32_t* sub_guess;     // [subs] start states offered from the stream context
     uint32_t* first_bad;     // [n] first sub-sequence that is not proven yet
     unsigned long long* ctx_keys;   // [ctx_slots] context hash table (power-of-two size): keys ...
     uint32_t* ctx_vals;             // ... and the start states remembered under them
@@ -255,7 +277,7 @@ struct DecodeScratch {
 
 // Small jobs the decoder's first kernel does on the side (both optional).  A launch at the head of the chain
 // costs more than its run time, because there the GPU waits for the host.
-constexpr uint32_t kSeedWords = 48;
+constexpr uint32_t kSeedWords = 48;   // = 3 * kPlanScanImages: jobs that small need no table either
 struct DecodePrologue {
     // The scan ranges as kernel arguments instead of a copy (which on a stream costs the latency of the copy
     // engine): 3 * n_images <= kSeedWords words -- offsets | sizes | unstuffed bases -- that the kernel uses and

@@ -384,6 +384,57 @@ def test_decode_batches_that_select_longer_subsequences(ctx, po, jea, copies):
         assert np.array_equal(got[i], want[i % 2]), i
 
 
+@pytest.mark.parametrize("n_images", [5, 16, 17, 40])
+def test_decode_batches_of_files_of_very_different_sizes(ctx, po, jea, n_images):
+    """Every file gets the workgroups its own scan needs (up to 16 files the kernels add up the files' counts
+    themselves, from 17 on they read a table made on the host): noise files ten times the size of the smooth
+    ones among them, in any position, through both decode entry points -- and a periodic file, which sends the
+    whole batch through the fallback decoder with its repair rounds."""
+    w, h, quality = 264, 200, 92
+    lum, chrom = jea.binding.quant_tables(quality)
+    kinds = [po.gen_image(w, h, 0, 3), po.gen_image(w, h, 1, 4), po.gen_image(w, h, 0, 5), po.gen_image(w, h, 1, 6)]
+    flat = np.full((h, w, 3), 90, np.uint8)
+    flat[:, ::16] = 180
+    for with_periodic in (False, True):
+        pictures = kinds + ([flat] if with_periodic else [])
+        files = [po.encode(im, quality) for im in pictures]
+        want = [po.decode(f, w, h, quality) for f in files]
+        pick = [(7 * i + i // 3) % len(files) for i in range(n_images)]
+        pick[0], pick[-1] = 1, 0          # a long file first, a short one last
+        offsets, sizes, blob = [], [], b""
+        for k in pick:
+            offsets.append(len(blob)); sizes.append(len(files[k]))
+            blob += files[k] + b"\0" * (-len(files[k]) % 64)
+        assert max(sizes) > 9 * min(sizes)
+        d_blob = ctx.to_device(np.frombuffer(blob, np.uint8))
+        got = ctx.decode_batch(d_blob, offsets, sizes, w, h, lum, chrom).cpu().numpy().reshape(n_images, h, w, 3)
+        for i, k in enumerate(pick):
+            assert np.array_equal(got[i], want[k]), (with_periodic, i, k)
+        # the scans alone, coefficients out in the standard layout
+        m = jea.binding.n_mcu(w, h)
+        coefs = ctx.entropy_decode(d_blob, [o + 607 for o in offsets], [s - 607 for s in sizes], m).cpu().numpy().reshape(n_images, m * 3, 64)
+        for i, k in enumerate(pick):
+            scan = files[k][607:]
+            assert np.array_equal(coefs[i], po.scan_to_coefs(scan, m)[0].reshape(m * 3, 64)), (with_periodic, i, k)
+
+
+def test_decode_uneven_batch_with_a_stream_beyond_the_folded_scan(ctx, po, jea):
+    """One file of more than 1024 workgroups (the write pass then gets its sums from a scan launch of its own)
+    beside files of a few workgroups."""
+    w, h, quality = 3840, 2160, 100
+    lum, chrom = jea.binding.quant_tables(quality)
+    pictures = [po.gen_image(w, h, 0, 41), po.gen_image(w, h, 1, 42), po.gen_image(w, h, 0, 43)]
+    files = [po.encode(im, quality) for im in pictures]
+    assert len(files[1]) > 1024 * 15360
+    offsets, sizes, blob = [], [], b""
+    for f in files:
+        offsets.append(len(blob)); sizes.append(len(f))
+        blob += f + b"\0" * (-len(f) % 64)
+    got = ctx.decode_batch(ctx.to_device(np.frombuffer(blob, np.uint8)), offsets, sizes, w, h, lum, chrom).cpu().numpy().reshape(3, h, w, 3)
+    for i, f in enumerate(files):
+        assert np.array_equal(got[i], po.decode(f, w, h, quality)), i
+
+
 def test_decode_periodic_streams(ctx, po, jea):
     """Flat and regularly patterned pictures give streams with a short period, in which a decoder that starts
     in a wrong state can stay out of phase for ever: the decoder's synchronisation then has to travel from
