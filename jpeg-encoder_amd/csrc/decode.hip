@@ -1512,7 +1512,15 @@ DecodePlan plan_entropy_decode(size_t n_images, const uint64_t* scan_sizes, size
     p.n_images = (uint32_t)n_images;
     p.n_chunks = (uint32_t)((max_scan_bytes + kChunkBytes - 1) / kChunkBytes);
     if (p.n_chunks == 0) p.n_chunks = 1;
-    // the longest sub-sequences that still give the GPU a few workgroups per compute unit
+    // the longest sub-sequences that still give the GPU a few workgroups per compute unit -- unless the streams are
+    // dense.  A decoder that starts in a wrong state falls into step only where a block ends, so the distance it
+    // needs grows with the blocks' length, and what the two rounds' 32 repair steps cover grows with the
+    // sub-sequences' length: one 1920x1080 picture of noise at quality 50 (145 bits per block) does not settle
+    // with 64-bit sub-sequences and went through the fallback decoder (0.81 ms), with 512-bit ones it settles.
+    // The time of such a stream is the serial walk over that distance whatever the sub-sequences' length, so the
+    // extra workgroups of the short ones would buy nothing either.
+    if (total_scan_bytes == 0) total_scan_bytes = max_scan_bytes * n_images;
+    const bool dense = (uint64_t)total_scan_bytes * 8 > 64ull * mcus_per_image * 3 * n_images;
     const uint32_t sizes[3] = {kSubWordsLarge, kSubWordsMedium, kSubWordsSmall};
     for (uint32_t w : sizes) {
         const uint32_t group_bytes = decode_group_bytes(w);
@@ -1525,20 +1533,20 @@ DecodePlan plan_entropy_decode(size_t n_images, const uint64_t* scan_sizes, size
             total = (uint64_t)p.n_groups * n_images;
         p.total_groups = (uint32_t)total;
 #ifdef JEA_PLAN_MIN_GROUPS   // experiments: tools/build_variant.sh <name> -DJEA_PLAN_MIN_GROUPS=<n>
-        if (total >= JEA_PLAN_MIN_GROUPS) break;
+        if (total >= JEA_PLAN_MIN_GROUPS || dense) break;
 #else
-        if (total >= 512) break;
+        if (total >= 512 || dense) break;
 #endif
     }
     p.subs_per_image = (size_t)p.n_groups * kOwned;
     p.total_subs = (size_t)p.total_groups * kOwned;
     p.mapped = n_images > kPlanScanImages;
+    p.dense = dense;
     p.total_blocks = (uint32_t)(mcus_per_image * 3);
     // Block records four at a time (BlockWriter::put_record): where the launch has workgroups with work to spare, and
     // not for pictures full of detail, where a thread has few blocks.  Write pass, records singly / in fours:
     // 256 smooth 1080p q=50 frames (1024 workgroups, 5 bits per block) 220 / 149 us, q=90 (4352; 21 bits) 879 / 813,
     // eight photo-like 4K pictures (1440; 55 bits) 277 / 281.5, one smooth 4K picture (180) level.
-    if (total_scan_bytes == 0) total_scan_bytes = max_scan_bytes * n_images;
     const uint64_t busy_groups = total_scan_bytes / ((uint64_t)kOwned * 4 * p.sub_words);
     p.records_in_fours = busy_groups >= 256 && (uint64_t)total_scan_bytes * 8 < 40ull * p.total_blocks * n_images;
     return p;
@@ -1649,6 +1657,12 @@ struct DecodeRun {
     hipError_t first_pass(const DecodeFollowUp& follow_up, DecodeReport* report) const {
         sync_round(1, sc.changed + 0, false);
         sync_round(0, sc.changed + 1, false);
+        // Dense streams synchronise late (see plan_entropy_decode): two more rounds of repair steps before the check.
+        // A round in which nothing is left to repair costs its launch, some 10 us.
+        if (p.dense) {
+            sync_round(0, sc.changed + 1, false);
+            sync_round(0, sc.changed + 1, false);
+        }
         if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[1], s);
         scan_and_write(sc.changed + 2);
         if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[2], s);

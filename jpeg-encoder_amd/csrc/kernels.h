@@ -228,6 +228,7 @@ struct DecodePlan {
     // More than kPlanScanImages images: the kernels find a workgroup's image in a table made on the host
     // (fill_group_map); up to that many they add up the images' workgroup counts themselves.
     bool mapped = false;
+    bool dense = false;         // more than 64 bits of stream per block-channel: long sub-sequences, four rounds
 };
 constexpr uint32_t kPlanScanImages = 16;
 // Raw scan bytes that one workgroup owns, for sub-sequences of sub_words words, and workgroups of a scan.
