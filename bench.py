@@ -662,16 +662,15 @@ def config_c4(job, steps=None, warmup=None, with_cpu=True):
     del image
     # the segment buffer is the caller's: smooth content stays far below 1.5 bytes per pixel (the worst case is 19)
     d_segment = torch.empty(3 * W * (y1 - y0) // 2 + (1 << 20), dtype=torch.uint8, device=job.dev)
-    backend = stripes.HipBackend(ctx, d_rgb, W, y1 - y0, lum, chrom, capacity=d_segment.numel(), d_segment=d_segment)
-    if job.dist is not None:
-        gather = stripes.dist_all_gather(job.dist, job.comm_device)
-    else:
-        gather = lambda values: [list(values)]
+    stripe = stripes.DeviceStripe(ctx, d_rgb, W, y1 - y0, lum, chrom, d_segment)
+    on_device = job.backend == "nccl"
     result = {}
 
     def step():
-        seg = stripes.encode_stripe(backend, job.rank, job.world, gather, W, H, on_device=True)
-        result["file"] = stripes.gather_segments_device(seg, job.dist, job.comm_device) if job.dist is not None else seg
+        # everything up to the sizes is enqueued on the context's stream without a wait: three steps, the exchanges
+        # between them (RCCL, device to device), the bit offset worked out on the GPU; collect_segments waits once
+        sizes = stripes.encode_stripe_on_stream(stripe, job.rank, job.world, job.dist, W, H, on_device)
+        result["file"] = stripes.collect_segments(stripe, sizes, job.rank, job.world, job.dist, on_device)
 
     step()
     checked = None
@@ -709,9 +708,11 @@ def config_c4(job, steps=None, warmup=None, with_cpu=True):
            "data": "synthetic smooth RGB8 (seed 1234), each rank's stripe resident in HBM",
            "config": {"workload": "single %dx%d image at q=75 as %d MCU-row stripe(s), one per rank; per step: transform, "
                                   "all-gather of DC predictors, bit strings, all-gather of bit counts and head bits, pack and "
-                                  "stuff, gather of the segments on rank 0" % (W, H, job.world),
+                                  "stuff at the bit offset computed on the GPU, all-gather of the segment sizes -- all enqueued on "
+                                  "one stream --, one host wait, segments sent to rank 0 at their exact sizes" % (W, H, job.world),
                       "width": W, "height": H, "quality": QUALITY, "stripe_rows": y1 - y0, "file_checked_against": checked,
-                      "collectives": "2 all-gathers of a few bytes + 1 gather of the segments per step (%s)" % job.backend,
+                      "collectives": "3 all-gathers of a few bytes + point-to-point sends of the segments per step (%s)" % job.comm_name,
+                      "host_waits_per_step": 1,
                       **region_stats(regions)},
            "roofline": roofline, "cpu_baseline": cpu}
     ctx.close()

@@ -236,6 +236,25 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
                       uint16_t image_width, uint16_t image_height, const uint16_t lum_q[64],
                       const uint16_t chr_q[64], uint8_t* d_segment, size_t capacity, size_t* segment_bytes);
 
+/* The same three steps for owners that exchange the facts from device memory to device memory (RCCL): every
+ * call only enqueues on the context's stream, nothing is copied to the host and nothing waits, so a rank enqueues
+ * transform, all-gather, bits, all-gather, finish and waits once at the end.  What replaces the host values:
+ *   d_last_dc        4 x int16: the last MCU's quantised DC values and a zero;
+ *   d_prev_dc        3 x int16 of the stripe above (e.g. inside the gathered array), NULL for the first stripe;
+ *   d_facts          2 x uint64 of this stripe: its bit count and its first 32 stream bits;
+ *   d_all_facts      n_stripes x 2 x uint64, every stripe's facts in stripe order: the bit offset of stripe
+ *                    stripe_index (the sum of the counts above it, as the serial encoder's stream position would
+ *                    be, bit_stream.cpp:44-67) and the head bits of the stripe below are taken from it on the GPU;
+ *   d_segment_bytes  1 x uint64: the segment's size;   d_status  1 x int32: 0 or a JEA_ERR_* code.
+ * Read d_segment_bytes and d_status after jea_synchronize() or from later work on the stream. */
+int jea_stripe_transform_async(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t width, uint16_t stripe_height,
+                               const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_last_dc);
+int jea_stripe_bits_async(jea_ctx* ctx, const int16_t* d_prev_dc, uint64_t* d_facts);
+int jea_stripe_finish_async(jea_ctx* ctx, const uint64_t* d_all_facts, uint32_t stripe_index, uint32_t n_stripes,
+                            uint16_t image_width, uint16_t image_height, const uint16_t lum_q[64],
+                            const uint16_t chr_q[64], uint8_t* d_segment, size_t capacity, uint64_t* d_segment_bytes,
+                            int32_t* d_status);
+
 /* ---- whole decode: Encoder::decode, encoder.cpp:44-71 ------------------ */
 
 /* Decodes n_images JPEG files produced by this encoder family (fixed header

@@ -18,6 +18,7 @@ EXPORTS = [
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
     "jea_encode_batch_static_async", "jea_static_scratch_needed", "jea_static_scratch_bytes",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
+    "jea_stripe_transform_async", "jea_stripe_bits_async", "jea_stripe_finish_async",
     "jea_decode_batch", "jea_decode_host",
     "jea_fdct_quant", "jea_fdct_quant_async", "jea_fdct_quant_planar_async", "jea_block_bit_lengths", "jea_entropy_encode", "jea_entropy_decode", "jea_remove_stuffing", "jea_idct_dequant",
     "jea_rgb_to_ycbcr", "jea_ycbcr_to_rgb",
@@ -82,6 +83,9 @@ def load_library():
     lib.jea_stripe_transform.argtypes = [vp, vp, u16, u16, vp, vp, vp]
     lib.jea_stripe_bits.argtypes = [vp, vp, c.POINTER(c.c_uint64), c.POINTER(c.c_uint32)]
     lib.jea_stripe_finish.argtypes = [vp, c.c_uint64, i32, i32, c.c_uint32, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
+    lib.jea_stripe_transform_async.argtypes = [vp, vp, u16, u16, vp, vp, vp]
+    lib.jea_stripe_bits_async.argtypes = [vp, vp, vp]
+    lib.jea_stripe_finish_async.argtypes = [vp, vp, c.c_uint32, c.c_uint32, u16, u16, vp, vp, vp, sz, vp, vp]
     lib.jea_decode_batch.argtypes = [vp, vp, vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_decode_host.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
     lib.jea_fdct_quant.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp]
@@ -424,6 +428,24 @@ class Context:
                                                image_h, lum.ctypes.data, chrom.ctypes.data, seg.data_ptr(), capacity,
                                                ctypes.byref(n)))
         return seg[: n.value]
+
+    # the same steps with the facts in device memory (tensors on this GPU); nothing waits
+    def stripe_transform_async(self, d_rgb_stripe, w, stripe_h, lum, chrom, d_last_dc):
+        self._need(d_rgb_stripe, 3 * w * stripe_h, "d_rgb_stripe")
+        self._need(d_last_dc, 4, "d_last_dc")
+        self._check(self.lib.jea_stripe_transform_async(self.handle, d_rgb_stripe.data_ptr(), w, stripe_h, lum.ctypes.data,
+                                                        chrom.ctypes.data, d_last_dc.data_ptr()))
+
+    def stripe_bits_async(self, d_prev_dc, d_facts):
+        self._need(d_facts, 2, "d_facts")
+        self._check(self.lib.jea_stripe_bits_async(self.handle, d_prev_dc.data_ptr() if d_prev_dc is not None else None,
+                                                   d_facts.data_ptr()))
+
+    def stripe_finish_async(self, d_all_facts, index, n_stripes, image_w, image_h, lum, chrom, d_segment, d_segment_bytes, d_status):
+        self._need(d_all_facts, 2 * n_stripes, "d_all_facts")
+        self._check(self.lib.jea_stripe_finish_async(self.handle, d_all_facts.data_ptr(), index, n_stripes, image_w, image_h,
+                                                     lum.ctypes.data, chrom.ctypes.data, d_segment.data_ptr(), d_segment.numel(),
+                                                     d_segment_bytes.data_ptr(), d_status.data_ptr()))
 
     # ---- whole path ----
     def encode_batch(self, d_rgb, n_images, w, h, lum, chrom, capacity=None, d_out=None):

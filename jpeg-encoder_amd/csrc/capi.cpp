@@ -1273,6 +1273,84 @@ int jea_stripe_finish(jea_ctx* ctx, uint64_t bits_before, int is_first, int has_
     return JEA_OK;
 }
 
+// The same three steps with the facts in device memory: nothing is copied to the host and nothing waits, so a
+// rank can enqueue step, exchange, step, exchange, step on one stream.
+
+int jea_stripe_transform_async(jea_ctx* ctx, const uint8_t* d_rgb_stripe, uint16_t width, uint16_t stripe_height,
+                               const uint16_t lum_q[64], const uint16_t chr_q[64], int16_t* d_last_dc) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_rgb_stripe || !d_last_dc || !valid_dims(width, stripe_height) || !tables_ok(lum_q, chr_q))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_transform_async: invalid argument");
+    if (ctx->optimal_huffman)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_transform_async: per-image Huffman tables are not available for stripes");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mcus = mcus_of(width, stripe_height);
+    int rc;
+    // all scratch of all three steps now (growing a buffer waits for the stream, which the later steps must not)
+    if ((rc = ensure(ctx, ctx->coefs, mcus * 3 * 64 * sizeof(int16_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->masks, mcus * 3))) return rc;
+    EntropyScratch sc;
+    const size_t worst = (mcus * 3 * 1660 + 7) / 8 + 64;
+    if ((rc = prepare_entropy_scratch(ctx, 1, mcus, worst, sc, true))) return rc;
+    if ((rc = ensure(ctx, ctx->small, 512))) return rc;
+    if ((rc = ensure(ctx, ctx->out_offsets, sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->out_sizes, sizeof(uint64_t)))) return rc;
+    int16_t* d_coefs = (int16_t*)ctx->coefs.ptr;
+    launch_fdct_quant(ctx->stream, d_rgb_stripe, 1, width, stripe_height, to_float_tables(lum_q, chr_q), d_coefs,
+                      ctx->d_status, (uint8_t*)ctx->masks.ptr, false, ctx->mode);
+    launch_stripe_last_dc(ctx->stream, d_coefs, mcus, d_last_dc);
+    JEA_HIP(ctx, hipGetLastError());
+    ctx->stripe_mcus = mcus;
+    ctx->stripe_height = stripe_height;
+    ctx->stripe_capacity = worst;
+    ctx->stripe_stage = 1;
+    return JEA_OK;
+}
+
+int jea_stripe_bits_async(jea_ctx* ctx, const int16_t* d_prev_dc, uint64_t* d_facts) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_facts) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_bits_async: invalid argument");
+    if (ctx->stripe_stage != 1) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_bits_async: call jea_stripe_transform_async first");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    EntropyScratch sc;
+    int rc;
+    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc, true))) return rc;
+    sc.chunk_masks = (const uint8_t*)ctx->masks.ptr;
+    launch_stripe_bits(ctx->stream, (const int16_t*)ctx->coefs.ptr, ctx->stripe_mcus, ctx->d_huff, sc, StripeInfo{},
+                       (uint32_t*)ctx->small.ptr, ctx->d_status, d_prev_dc, d_facts);
+    JEA_HIP(ctx, hipGetLastError());
+    ctx->stripe_stage = 2;
+    return JEA_OK;
+}
+
+int jea_stripe_finish_async(jea_ctx* ctx, const uint64_t* d_all_facts, uint32_t stripe_index, uint32_t n_stripes,
+                            uint16_t image_width, uint16_t image_height, const uint16_t lum_q[64],
+                            const uint16_t chr_q[64], uint8_t* d_segment, size_t capacity, uint64_t* d_segment_bytes,
+                            int32_t* d_status) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!d_all_facts || !d_segment || !d_segment_bytes || !d_status || capacity == 0 || n_stripes == 0 ||
+        stripe_index >= n_stripes || !tables_ok(lum_q, chr_q) || !valid_dims(image_width, image_height))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_finish_async: invalid argument");
+    if (ctx->stripe_stage != 2) return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_finish_async: call jea_stripe_bits_async first");
+    const bool is_first = stripe_index == 0, has_next = stripe_index + 1 < n_stripes;
+    if (has_next && ctx->stripe_height % 8 != 0)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_stripe_finish_async: only the last stripe may have a height that is not a multiple of 8");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    EntropyScratch sc;
+    int rc;
+    if ((rc = prepare_entropy_scratch(ctx, 1, ctx->stripe_mcus, ctx->stripe_capacity, sc, true))) return rc;
+    StripeInfo* d_st = (StripeInfo*)((uint8_t*)ctx->small.ptr + 256);
+    launch_stripe_place(ctx->stream, d_all_facts, stripe_index, n_stripes, d_st);
+    HeaderBytes hb{};
+    if (is_first) jea_write_header(hb.b, image_width, image_height, lum_q, chr_q);
+    launch_stripe_finish(ctx->stream, ctx->stripe_mcus, sc, StripeInfo{}, hb, is_first ? JEA_HEADER_BYTES : 0, !has_next,
+                         d_segment, capacity, (uint64_t*)ctx->out_offsets.ptr, d_segment_bytes, ctx->d_status, d_st);
+    JEA_HIP(ctx, hipGetLastError());
+    JEA_HIP(ctx, hipMemcpyAsync(d_status, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->stripe_stage = 0;
+    return JEA_OK;
+}
+
 // ---- decode -------------------------------------------------------------------
 
 // Uploads the scan ranges (file ranges minus `skip` leading header bytes), sizes the scratch of the

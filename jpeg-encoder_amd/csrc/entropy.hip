@@ -83,7 +83,8 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
                                                                  uint32_t* __restrict__ slots,
                                                                  int32_t* __restrict__ status, StripeInfo st,
                                                                  const uint8_t* __restrict__ chunk_masks,
-                                                                 ComponentMode mode) {
+                                                                 ComponentMode mode,
+                                                                 const int16_t* __restrict__ d_initial_dc = nullptr) {
     __shared__ HuffLds h;
     __shared__ uint32_t wsum[4];
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
         // stripe, at the last MCU of the stripe above
         const int16_t* p = coefs + ((size_t)img * nbc + b) * 64;
         load_block(blk, p, chunk_masks != nullptr ? (uint32_t)chunk_masks[(size_t)img * nbc + b] : 0xffu);
-        prev_dc = (b >= 3) ? (int)p[-192] : (int)st.initial_dc[b];
+        // (d_initial_dc: the same three values in device memory, where another stripe's owner has put them)
+        prev_dc = (b >= 3) ? (int)p[-192] : (d_initial_dc != nullptr ? (int)d_initial_dc[b] : (int)st.initial_dc[b]);
     }
     load_huff<kEntThreads>(h, huff);
     __syncthreads();
@@ -151,30 +153,70 @@ __device__ __forceinline__ uint64_t align_up(uint64_t v, uint64_t a) { return (v
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t* __restrict__ in, uint32_t n_tiles,
                                                           uint64_t* __restrict__ out,
                                                           uint64_t* __restrict__ img_total, ImageLevel lvl) {
-    __shared__ uint64_t wave_sum[16];
-    __shared__ uint64_t carry_s;
+    __shared__ uint64_t wave_sum[2][16];
     const uint32_t img = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint64_t v = (t < n_tiles) ? (uint64_t)in[(size_t)img * n_tiles + t] : 0;
+    // 4096 tiles per step, four consecutive ones per thread: one 16-byte load and two 16-byte stores per thread, all
+    // of a wave's next to one another, the next step's load asked for before this step's scan, and one barrier per
+    // step (the waves' sums alternate between two buffers).  A stripe of 50 000 tiles took 76 us with one tile per
+    // thread and step; a run of 49 consecutive tiles per thread, whose accesses do not coalesce, 100 us.
+    const uint32_t* src = in + (size_t)img * n_tiles;
+    uint64_t* dst = out + (size_t)img * n_tiles;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15u) | (reinterpret_cast<uintptr_t>(dst) & 15u)) == 0;
+    auto load4 = [&](uint32_t at) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (at < n_tiles) {
+            if (aligned && at + 4u <= n_tiles) {
+                q = *reinterpret_cast<const uint4*>(src + at);
+            } else {
+                q.x = src[at];
+                if (at + 1u < n_tiles) q.y = src[at + 1u];
+                if (at + 2u < n_tiles) q.z = src[at + 2u];
+                if (at + 3u < n_tiles) q.w = src[at + 3u];
+            }
+        }
+        return q;
+    };
+    uint64_t carry = 0;   // every thread keeps the running total itself
+    uint4 next = load4(4u * threadIdx.x);
+    uint32_t step = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 4096u, ++step) {
+        const uint32_t at = t0 + 4u * threadIdx.x;
+        const uint4 q = next;
+        if (t0 + 4096u < n_tiles) next = load4(at + 4096u);
+        const uint64_t v = (uint64_t)q.x + q.y + q.z + q.w;
         uint64_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t u = __shfl_up(incl, d);
             if (lane >= d) incl += u;
         }
-        if (lane == 63) wave_sum[wave] = incl;
+        uint64_t* ws = wave_sum[step & 1u];
+        if (lane == 63) ws[wave] = incl;
         __syncthreads();
-        uint64_t base = carry_s;
-        for (int w = 0; w < wave; ++w) base += wave_sum[w];
-        if (t < n_tiles) out[(size_t)img * n_tiles + t] = base + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = base + incl;
-        __syncthreads();
+        uint64_t base = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint64_t x = ws[w];
+            base += w < wave ? x : 0;
+            all += x;
+        }
+        carry += all;
+        if (at < n_tiles) {
+            const uint64_t e0 = base + incl - v, e1 = e0 + q.x, e2 = e1 + q.y, e3 = e2 + q.z;
+            if (aligned && at + 4u <= n_tiles) {
+                *reinterpret_cast<ulonglong2*>(dst + at) = make_ulonglong2(e0, e1);
+                *reinterpret_cast<ulonglong2*>(dst + at + 2) = make_ulonglong2(e2, e3);
+            } else {
+                dst[at] = e0;
+                if (at + 1u < n_tiles) dst[at + 1u] = e1;
+                if (at + 2u < n_tiles) dst[at + 2u] = e2;
+                if (at + 3u < n_tiles) dst[at + 3u] = e3;
+            }
+        }
     }
+    __shared__ uint64_t carry_s;
+    if (threadIdx.x == 0) carry_s = carry;
     if (threadIdx.x == 0) {
         const uint64_t total = carry_s;
         img_total[img] = total;
@@ -247,10 +289,12 @@ __global__ __launch_bounds__(kEntThreads) void pack_kernel(uint32_t nbc, uint32_
                                                            uint8_t* __restrict__ unstuffed,
                                                            uint64_t unstuffed_capacity,
                                                            uint32_t* __restrict__ tile_ff,
-                                                           int32_t* __restrict__ status, StripeInfo st) {
+                                                           int32_t* __restrict__ status, StripeInfo st,
+                                                           const StripeInfo* __restrict__ d_st = nullptr) {
     __shared__ uint32_t win[kWinWords + 2];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t ff_count;
+    if (d_st != nullptr) st = *d_st;   // the stripe's place in the stream, worked out on the device (stripe_place_kernel)
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const int32_t status_now = *status;                       // looked at after the other loads are under way
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
@@ -338,8 +382,10 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
                                                             uint64_t* __restrict__ sizes, HeaderBytes header,
                                                             uint32_t header_len, uint32_t with_eoi,
                                                             uint8_t* __restrict__ out, uint64_t out_capacity,
-                                                            int32_t* __restrict__ status, StripeInfo st) {
+                                                            int32_t* __restrict__ status, StripeInfo st,
+                                                            const StripeInfo* __restrict__ d_st = nullptr) {
     __shared__ uint32_t wsum[4];
+    if (d_st != nullptr) st = *d_st;
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     if (*status != 0) return;
     const uint64_t* tb = tile_base + (size_t)img * n_tiles;
@@ -1097,8 +1143,11 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
 
 namespace {
 // First 32 bits (MSB first, zero padded) of the stream that the blocks' strings form.
+// d_facts (may be null): also leaves {the stripe's bit count, its head bits} there as two 64-bit words -- what the
+// stripes' owners exchange before the last step.
 __global__ void stripe_head_kernel(const uint16_t* __restrict__ len16, const uint32_t* __restrict__ slots,
-                                   uint32_t nbc, uint32_t* __restrict__ head) {
+                                   uint32_t nbc, uint32_t* __restrict__ head, const uint64_t* __restrict__ img_bits,
+                                   uint64_t* __restrict__ d_facts) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t acc = 0, n = 0;
     for (uint32_t b = 0; b < nbc && n < 32; ++b) {
@@ -1110,37 +1159,76 @@ __global__ void stripe_head_kernel(const uint16_t* __restrict__ len16, const uin
         }
     }
     *head = acc;
+    if (d_facts != nullptr) {
+        d_facts[0] = img_bits[0];
+        d_facts[1] = acc;
+    }
+}
+
+// The last MCU's quantised DC values (Y, Cb, Cr; a fourth word of padding) for the owner of the stripe below.
+__global__ void stripe_last_dc_kernel(const int16_t* __restrict__ coefs, uint32_t mcus, int16_t* __restrict__ d_last_dc) {
+    if (threadIdx.x < 4) d_last_dc[threadIdx.x] = threadIdx.x < 3 ? coefs[((size_t)(mcus - 1) * 3 + threadIdx.x) * 64] : (int16_t)0;
+}
+
+// Where stripe `index` of `n` lies in the image's stream, from every stripe's {bit count, head bits}: the sum of the
+// bit counts above it (bit_stream.cpp:44-67 appends, so a stripe starts where the one before ends) and the head bits
+// of the stripe below.  One wave; the stripes are few.
+__global__ void stripe_place_kernel(const uint64_t* __restrict__ facts, uint32_t index, uint32_t n, StripeInfo* __restrict__ st) {
+    uint64_t before = 0;
+    for (uint32_t r = threadIdx.x; r < index; r += 64) before += facts[2 * (size_t)r];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+    if (threadIdx.x != 0) return;
+    StripeInfo s{};
+    s.bit_base = before;
+    s.first_byte = (before + 7) >> 3;
+    s.origin_byte = s.first_byte & ~uint64_t(3);
+    s.has_next = index + 1 < n ? 1u : 0u;
+    s.next_head = s.has_next ? (uint32_t)facts[2 * (size_t)(index + 1) + 1] : 0u;
+    s.active = 1;
+    *st = s;
 }
 }  // namespace
 
+void launch_stripe_last_dc(hipStream_t s, const int16_t* d_coefs, size_t mcus, int16_t* d_last_dc) {
+    stripe_last_dc_kernel<<<1, 64, 0, s>>>(d_coefs, (uint32_t)mcus, d_last_dc);
+}
+
 void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, const HuffTables* d_huff,
-                        const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status) {
+                        const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status,
+                        const int16_t* d_initial_dc, uint64_t* d_facts) {
     const uint32_t nbc = (uint32_t)(mcus * 3);
     const uint32_t n_tiles = tiles_per_image(mcus);
     block_bits_kernel<true><<<dim3(n_tiles, 1), kEntThreads, 0, s>>>(d_coefs, nbc, n_tiles, d_huff, sc.len16, sc.tile_bits,
-                                                                     sc.slots, d_status, st, sc.chunk_masks, sc.mode);
+                                                                     sc.slots, d_status, st, sc.chunk_masks, sc.mode,
+                                                                     d_initial_dc);
     ImageLevel l1{1, nullptr, sc.img_ubase, nullptr, (uint64_t)sc.unstuffed_capacity, 0, d_status};
     scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_bits, n_tiles, sc.tile_base, sc.img_bits, l1);
-    stripe_head_kernel<<<1, 64, 0, s>>>(sc.len16, sc.slots, nbc, d_head);
+    stripe_head_kernel<<<1, 64, 0, s>>>(sc.len16, sc.slots, nbc, d_head, sc.img_bits, d_facts);
+}
+
+void launch_stripe_place(hipStream_t s, const uint64_t* d_all_facts, uint32_t index, uint32_t n_stripes, StripeInfo* d_st) {
+    stripe_place_kernel<<<1, 64, 0, s>>>(d_all_facts, index, n_stripes, d_st);
 }
 
 void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, const StripeInfo& st,
                           const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
-                          size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status) {
+                          size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status,
+                          const StripeInfo* d_st) {
     const uint32_t nbc = (uint32_t)(mcus * 3);
     const uint32_t n_tiles = tiles_per_image(mcus);
     const dim3 grid(n_tiles, 1);
     const uint32_t eoi = with_eoi ? 1u : 0u;
     pack_kernel<<<grid, kEntThreads, 0, s>>>(nbc, n_tiles, sc.slots, sc.len16, sc.tile_bits, sc.tile_base,
                                                     sc.img_bits, sc.img_ubase, sc.unstuffed, sc.unstuffed_capacity,
-                                                    sc.tile_ff, d_status, st);
+                                                    sc.tile_ff, d_status, st, d_st);
     // the scan's own size estimate is only a capacity check here; the stuff pass writes the exact segment size
     ImageLevel l2{2, sc.img_bits, d_offsets, d_sizes, (uint64_t)out_capacity + 8, (uint32_t)header_len + 2 * eoi, d_status};
     scan_tiles_kernel<<<1, 1024, 0, s>>>(sc.tile_ff, n_tiles, sc.tile_ffbase, sc.img_ff, l2);
     stuff_kernel<<<grid, kEntThreads, 0, s>>>(n_tiles, sc.tile_bits, sc.tile_base, sc.img_bits, sc.img_ubase,
                                                      sc.unstuffed, sc.tile_ff, sc.tile_ffbase, sc.img_ff, d_offsets,
                                                      d_sizes, header, (uint32_t)header_len, eoi, d_out, out_capacity,
-                                                     d_status, st);
+                                                     d_status, st, d_st);
 }
 
 }  // namespace jea

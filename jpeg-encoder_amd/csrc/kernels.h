@@ -203,11 +203,22 @@ void launch_entropy_encode(hipStream_t s, const int16_t* d_coefs, size_t n_image
 // bits: block bit strings (DC chain continued from st.initial_dc), per-tile scan,
 //       total -> sc.img_bits[0], first 32 stream bits -> d_head;
 // finish: pack at st.bit_base, 0xFF scan, stuffed segment (+ header / EOI) -> d_out, size -> d_sizes[0].
+// The facts that travel between the stripes' owners may stay in device memory (so that a rank enqueues all steps and
+// the exchanges between them without waiting for the GPU):
+//   launch_stripe_last_dc: the last MCU's quantised DC values -> d_last_dc[0..2] (d_last_dc[3] = 0);
+//   d_initial_dc (may be null): the DC start in device memory instead of st.initial_dc;
+//   d_facts (may be null): {bit count, head bits} of the stripe as two 64-bit words;
+//   launch_stripe_place: from all stripes' facts ([n_stripes][2]) the StripeInfo of stripe `index` -> *d_st;
+//   d_st (may be null): the StripeInfo in device memory instead of st.
+void launch_stripe_last_dc(hipStream_t s, const int16_t* d_coefs, size_t mcus, int16_t* d_last_dc);
 void launch_stripe_bits(hipStream_t s, const int16_t* d_coefs, size_t mcus, const HuffTables* d_huff,
-                        const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status);
+                        const EntropyScratch& sc, const StripeInfo& st, uint32_t* d_head, int32_t* d_status,
+                        const int16_t* d_initial_dc = nullptr, uint64_t* d_facts = nullptr);
+void launch_stripe_place(hipStream_t s, const uint64_t* d_all_facts, uint32_t index, uint32_t n_stripes, StripeInfo* d_st);
 void launch_stripe_finish(hipStream_t s, size_t mcus, const EntropyScratch& sc, const StripeInfo& st,
                           const HeaderBytes& header, int header_len, bool with_eoi, uint8_t* d_out,
-                          size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status);
+                          size_t out_capacity, uint64_t* d_offsets, uint64_t* d_sizes, int32_t* d_status,
+                          const StripeInfo* d_st = nullptr);
 
 // Parallel Huffman decode (decode.hip).  The scan of image i is the byte range
 // [d_offsets[i], d_offsets[i] + d_sizes[i]) of d_scan and ends with the EOI marker.

@@ -128,3 +128,134 @@ def gather_segments_device(segment, dist, device, dst=0):
     if rank != dst:
         return None
     return torch.cat([parts[r][: sizes[r][0]] for r in range(world)])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The same protocol with the facts kept in device memory: a rank enqueues all three steps and the two exchanges
+# between them on its context's stream and waits once, when it needs the segments' sizes on the host.
+# ---------------------------------------------------------------------------------------------------------
+
+class DeviceStripe:
+    """One rank's stripe through the device-argument entry points (jea_stripe_*_async).  Holds the small device
+    buffers the steps write: the last MCU's DC values, the stripe's {bit count, head bits}, the segment's size, the
+    status word."""
+
+    def __init__(self, ctx, d_rgb_stripe, width, stripe_height, lum, chrom, d_segment):
+        import torch
+
+        self.ctx, self.d_rgb, self.w, self.h, self.lum, self.chrom, self.d_segment = ctx, d_rgb_stripe, width, stripe_height, lum, chrom, d_segment
+        dev = ctx.tdev
+        self.d_dc = torch.zeros(4, dtype=torch.int16, device=dev)
+        self.d_facts = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.d_size = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # torch's view of the context's stream: collectives issued under it are ordered with the library's kernels
+        self.stream = torch.cuda.ExternalStream(ctx.stream_handle, device=dev)
+        self.keep = []   # gathered tensors that enqueued kernels still read
+        torch.cuda.synchronize(dev)
+
+
+def _gather_on_device(t, dist, on_device):
+    """[world, t.numel()] on t's device: all ranks' copies of the small tensor t, in rank order.  With RCCL the
+    exchange is device to device on the current stream; with another backend (gloo in the rehearsals) it goes
+    through the host."""
+    import torch
+
+    if dist is None:
+        return t.reshape(1, -1)
+    world = dist.get_world_size()
+    raw = t.reshape(-1).view(torch.uint8)      # bytes on the wire: not every backend knows 16-bit integers
+    if on_device:
+        out = torch.empty(world * raw.numel(), dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(out, raw)
+        return out.view(t.dtype).reshape(world, -1)
+    mine = raw.cpu()
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return torch.stack(parts).to(t.device).view(t.dtype).reshape(world, -1)
+
+
+def encode_stripe_on_stream(stripe, rank, world, dist, image_w, image_h, on_device=True):
+    """What one rank enqueues: transform, all-gather of the DC values, bit strings, all-gather of {bit count, head
+    bits}, pack and stuff at the bit offset worked out on the GPU, all-gather of the segment sizes.  Returns the
+    sizes ([world] int64, device) without waiting for anything (on_device: the exchanges are RCCL's)."""
+    import torch
+
+    ctx = stripe.ctx
+    with torch.cuda.stream(stripe.stream):
+        ctx.stripe_transform_async(stripe.d_rgb, stripe.w, stripe.h, stripe.lum, stripe.chrom, stripe.d_dc)
+        all_dc = _gather_on_device(stripe.d_dc, dist, on_device)
+        ctx.stripe_bits_async(all_dc[rank - 1] if rank > 0 else None, stripe.d_facts)
+        all_facts = _gather_on_device(stripe.d_facts, dist, on_device)
+        ctx.stripe_finish_async(all_facts, rank, world, image_w, image_h, stripe.lum, stripe.chrom, stripe.d_segment,
+                                stripe.d_size, stripe.d_status)
+        sizes = _gather_on_device(stripe.d_size, dist, on_device).reshape(-1)
+    stripe.keep = [all_dc, all_facts, sizes]
+    return sizes
+
+
+def collect_segments(stripe, sizes, rank, world, dist, on_device=True, dst=0):
+    """The one wait of a step: the sizes come to the host (and with them the status), then every segment travels
+    to rank `dst` at its exact size, straight to its place in the file.  Returns the file (uint8 tensor; on the GPU
+    with RCCL) on rank `dst`, None elsewhere."""
+    import torch
+
+    with torch.cuda.stream(stripe.stream):
+        host_sizes = [int(v) for v in sizes.cpu()]          # waits for the stream
+        status = int(stripe.d_status.item())
+    if status != 0:
+        raise RuntimeError("stripe encode reported status %d" % status)
+    mine = stripe.d_segment[: host_sizes[rank]]
+    if dist is None or world == 1:
+        return mine
+    if not on_device:
+        mine = mine.cpu()
+    if rank != dst:
+        dist.send(mine, dst=dst)
+        return None
+    file = torch.empty(sum(host_sizes), dtype=torch.uint8, device=mine.device)
+    at = 0
+    pending = []
+    for r in range(world):
+        part = file[at: at + host_sizes[r]]
+        if r == dst:
+            part.copy_(mine)
+        else:
+            pending.append(dist.irecv(part, src=r))
+        at += host_sizes[r]
+    for p in pending:
+        p.wait()
+    return file
+
+
+def encode_in_process_on_device(stripes_of_image, image_w, image_h):
+    """All stripes in one process through the device-argument entry points (DeviceStripe objects on contexts of one
+    GPU): the exchanges are tensor copies on that GPU.  Returns the file as bytes."""
+    import torch
+
+    world = len(stripes_of_image)
+
+    def wait_all():
+        for s in stripes_of_image:
+            s.ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for s in stripes_of_image:
+        s.ctx.stripe_transform_async(s.d_rgb, s.w, s.h, s.lum, s.chrom, s.d_dc)
+    wait_all()
+    all_dc = torch.stack([s.d_dc for s in stripes_of_image])
+    torch.cuda.synchronize()
+    for r, s in enumerate(stripes_of_image):
+        s.ctx.stripe_bits_async(all_dc[r - 1] if r > 0 else None, s.d_facts)
+    wait_all()
+    all_facts = torch.stack([s.d_facts for s in stripes_of_image]).reshape(-1)
+    torch.cuda.synchronize()
+    for r, s in enumerate(stripes_of_image):
+        s.ctx.stripe_finish_async(all_facts, r, world, image_w, image_h, s.lum, s.chrom, s.d_segment, s.d_size, s.d_status)
+    wait_all()
+    out = []
+    for s in stripes_of_image:
+        if int(s.d_status.item()) != 0:
+            raise RuntimeError("stripe encode reported status %d" % int(s.d_status.item()))
+        out.append(s.d_segment[: int(s.d_size.item())].cpu().numpy().tobytes())
+    return b"".join(out)

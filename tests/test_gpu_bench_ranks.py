@@ -18,7 +18,7 @@ def _bench(*argv, **env_extra):
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=110)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.returncode == 0, r.stdout[-2000:] + "\n".join(ln for ln in r.stderr.splitlines() if ln.startswith("[rank"))[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0])

@@ -63,6 +63,12 @@ def test_c4_gigapixel_as_eight_stripes(jea, po, gigapixel):
                     for c, (y0, y1) in zip(ctxs, rows)]
         jpeg = stripes.encode_in_process(backends, w, h)
         assert len(jpeg) == r["jpeg_bytes"] and po.fnv(jpeg) == r["jpeg_fnv"]
+        del jpeg
+        # and through the entry points that keep the exchanged facts in device memory (what bench.py --config c4 runs)
+        on_device = [stripes.DeviceStripe(c, b.d_rgb, w, b.h, lum, chrom, c.empty(3 * w * b.h // 2 + (1 << 20), c.torch.uint8))
+                     for c, b in zip(ctxs, backends)]
+        jpeg = stripes.encode_in_process_on_device(on_device, w, h)
+        assert len(jpeg) == r["jpeg_bytes"] and po.fnv(jpeg) == r["jpeg_fnv"]
     finally:
         for c in ctxs:
             c.close()

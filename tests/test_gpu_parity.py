@@ -686,10 +686,20 @@ def test_striped_encode_equals_whole_image(ctx, po, jea, w, h, n_stripes, mode, 
         backends = [stripes.HipBackend(c, c.to_device(rgb[y0:y1].reshape(-1)), w, y1 - y0, lum, chrom)
                     for c, (y0, y1) in zip(ctxs, rows)]
         got = stripes.encode_in_process(backends, w, h)
+        # the same through the entry points that take and leave the exchanged facts in device memory
+        on_device = [stripes.DeviceStripe(c, b.d_rgb, w, b.h, lum, chrom, c.empty(_segment_room(jea, w, b.h), c.torch.uint8))
+                     for c, b in zip(ctxs, backends)]
+        got_device = stripes.encode_in_process_on_device(on_device, w, h)
     finally:
         for c in ctxs:
             c.close()
-    assert got == po.encode(rgb, quality)
+    want = po.encode(rgb, quality)
+    assert got == want
+    assert got_device == want
+
+
+def _segment_room(jea, w, stripe_h):
+    return 607 + 2 * ((jea.binding.n_mcu(w, stripe_h) * 3 * 1660 + 7) // 8) + 16
 
 
 def test_striped_encode_all_ff_boundaries(ctx, po, jea):
@@ -710,6 +720,9 @@ def test_striped_encode_all_ff_boundaries(ctx, po, jea):
             backends = [stripes.HipBackend(c, c.to_device(rgb[y0:y1].reshape(-1)), w, y1 - y0, lum, chrom)
                         for c, (y0, y1) in zip(ctxs, rows)]
             assert stripes.encode_in_process(backends, w, h) == want, n
+            on_device = [stripes.DeviceStripe(c, b.d_rgb, w, b.h, lum, chrom, c.empty(_segment_room(jea, w, b.h), c.torch.uint8))
+                         for c, b in zip(ctxs, backends)]
+            assert stripes.encode_in_process_on_device(on_device, w, h) == want, n
         finally:
             for c in ctxs:
                 c.close()
