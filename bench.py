@@ -278,6 +278,64 @@ def forward_kernel_roofline(job, ctx, groups, whole, w, h, lum, chrom, images_pe
     return roof, one
 
 
+def host_batch_rates(job, ctx, imgs, w, h, quality, lum, chrom, po, n=64):
+    """jea_encode_host_batch / jea_decode_host_batch on n pictures held in host memory, beside what the link itself does
+    (pinned memory to device, measured here).  PCIe both ways inside the timed calls; never `value`."""
+    import numpy as np
+
+    torch = job.torch
+    # the link: pinned host memory -> device, 256 MB at a time
+    pin = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+    dev = torch.empty(256 << 20, dtype=torch.uint8, device=job.dev)
+    dev.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(job.dev)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        dev.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(job.dev)
+    h2d = 8 * pin.numel() / (time.perf_counter() - t0) / 1e9
+    t0 = time.perf_counter()
+    for _ in range(8):
+        pin.copy_(dev, non_blocking=True)
+    torch.cuda.synchronize(job.dev)
+    d2h = 8 * pin.numel() / (time.perf_counter() - t0) / 1e9
+    del pin, dev
+    res = {"images": n, "link_pinned_h2d_GBps": round(h2d, 1), "link_pinned_d2h_GBps": round(d2h, 1),
+           "link_ceiling_MPix/s_at_3_bytes_per_pixel": round(h2d * 1e3 / 3, 1)}
+    per = 3 * w * h
+    cap = n * (per // 8)           # smooth pictures: far below 3/8 byte per pixel
+    for name, pinned in (("pageable", False), ("pinned", True)):
+        if pinned:
+            rgb, out, back = ctx.host_array(n * per), ctx.host_array(cap), ctx.host_array(n * per)
+        else:
+            rgb, out, back = np.empty(n * per, np.uint8), np.empty(cap, np.uint8), np.zeros(n * per, np.uint8)
+            back[:] = 1      # the caller's pages exist before the timed call (first touches would be timed as copies)
+        rgb = rgb.reshape(n, h, w, 3)
+        for i in range(n):
+            rgb[i] = imgs[i % len(imgs)]
+        ctx.encode_host_batch(rgb[:4], lum, chrom, out=out)      # staging buffers and scratch exist after this
+        t0 = time.perf_counter()
+        _, off, size = ctx.encode_host_batch(rgb, lum, chrom, out=out)
+        t_enc = time.perf_counter() - t0
+        ok = all(out[int(off[i]): int(off[i] + size[i])].tobytes() == po.encode(imgs[i % len(imgs)], quality) for i in (0, n - 1))
+        ctx.decode_host_batch(out, off[:4], size[:4], w, h, lum, chrom, out=back)
+        t0 = time.perf_counter()
+        got = ctx.decode_host_batch(out, off, size, w, h, lum, chrom, out=back)
+        t_dec = time.perf_counter() - t0
+        ok = ok and np.array_equal(got[n - 1], po.decode(out[int(off[n - 1]): int(off[n - 1] + size[n - 1])].tobytes(), w, h, quality))
+        res[name + "_caller_memory"] = {
+            "encode_MPix/s": round(n * w * h / t_enc / 1e6, 1), "encode_input_GBps": round(n * per / t_enc / 1e9, 1),
+            "encode_fraction_of_link": round(n * per / t_enc / 1e9 / h2d, 3),
+            "decode_MPix/s": round(n * w * h / t_dec / 1e6, 1), "decode_output_GBps": round(n * per / t_dec / 1e9, 1),
+            "decode_fraction_of_link": round(n * per / t_dec / 1e9 / d2h, 3), "identical_to_oracle_sampled": bool(ok)}
+        if pinned:
+            for a in (rgb.reshape(-1), out, back):
+                ctx.host_free(a)
+    res["note"] = ("%d pictures of %dx%d in host memory per call; pieces of about 32 MB on two staging slots, link, kernels and the "
+                   "way back overlapped; pinned = memory from jea_host_malloc, which the GPU reads and writes directly" % (n, w, h))
+    return res
+
+
 class ImagePool(list):
     """Device-resident images: pool[i] is image i; pool.whole is the one buffer that holds them back to back."""
 
@@ -466,6 +524,7 @@ def config_c2(job):
             ctx.encode_host(imgs[i % len(imgs)], lum, chrom)
         out["host_to_host"] = {"MPix/s": round(n_h2h * W * H / (time.perf_counter() - t0) / 1e6, 1),
                                "note": "jea_encode_host: 24.9 MB of pageable host memory in over PCIe, file back out; one context"}
+        out["host_to_host"]["batch"] = host_batch_rates(job, ctx, imgs, W, H, QUALITY, lum, chrom, po)
     out["cpu_baseline"] = cpu
     for c in ctxs:
         c.close()

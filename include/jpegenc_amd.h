@@ -211,6 +211,22 @@ int jea_encode_host(jea_ctx* ctx, const uint8_t* h_rgb, uint16_t width, uint16_t
                     const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* h_out, size_t out_capacity,
                     size_t* out_len);
 
+/* Batches held in host memory, as the reference's caller holds them (examples/encode-decode.cpp:104-118): n_images
+ * bitmaps back to back in, files out at 64-byte aligned offsets (h_offsets / h_sizes as jea_encode_batch returns them) --
+ * and the reverse.  The batch goes through the GPU in pieces of about 32 MB of pixels on two staging slots: the next
+ * piece's way over the link, the kernels of the current piece and the way back of the piece before overlap.  Caller
+ * memory from jea_host_malloc (pinned) is read and written by the GPU directly; other memory is copied through the
+ * context's pinned staging buffers by a few host threads.  Both calls return when the results are complete. */
+int jea_encode_host_batch(jea_ctx* ctx, const uint8_t* h_rgb, size_t n_images, uint16_t width, uint16_t height,
+                          const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* h_out, size_t out_capacity,
+                          uint64_t* h_offsets, uint64_t* h_sizes);
+int jea_decode_host_batch(jea_ctx* ctx, const uint8_t* h_jpeg, const uint64_t* h_offsets, const uint64_t* h_sizes,
+                          size_t n_images, uint16_t width, uint16_t height, const uint16_t lum_q[64],
+                          const uint16_t chr_q[64], uint8_t* h_rgb);
+/* Pinned host memory for the calls above (hipHostMalloc / hipHostFree). */
+int jea_host_malloc(jea_ctx* ctx, size_t bytes, void** h_ptr);
+int jea_host_free(jea_ctx* ctx, void* h_ptr);
+
 /* ---- one image as MCU-row stripes on several contexts / GPUs -----------
  * The reference codes an image as one serial chain (encoder.cpp:20-28): the DC
  * predictors and the bit position carry from MCU to MCU.  A stripe (a run of

@@ -16,6 +16,7 @@ EXPORTS = [
     "jea_set_profiling", "jea_last_phase_ms", "jea_set_scratch_budget", "jea_set_huffman_optimised",
     "jea_quant_tables", "jea_write_header", "jea_max_jpeg_bytes", "jea_check_header", "jea_read_header", "jea_read_header_ex",
     "jea_encode_batch", "jea_encode_batch_async", "jea_encode_host",
+    "jea_encode_host_batch", "jea_decode_host_batch", "jea_host_malloc", "jea_host_free",
     "jea_encode_batch_static_async", "jea_static_scratch_needed", "jea_static_scratch_bytes",
     "jea_stripe_transform", "jea_stripe_bits", "jea_stripe_finish",
     "jea_stripe_transform_async", "jea_stripe_bits_async", "jea_stripe_finish_async",
@@ -75,6 +76,10 @@ def load_library():
     lib.jea_encode_batch.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp]
     lib.jea_encode_batch_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
     lib.jea_encode_host.argtypes = [vp, vp, u16, u16, vp, vp, vp, sz, c.POINTER(sz)]
+    lib.jea_encode_host_batch.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp]
+    lib.jea_decode_host_batch.argtypes = [vp, vp, vp, vp, sz, u16, u16, vp, vp, vp]
+    lib.jea_host_malloc.argtypes = [vp, sz, c.POINTER(vp)]
+    lib.jea_host_free.argtypes = [vp, vp]
     lib.jea_encode_batch_static_async.argtypes = [vp, vp, sz, u16, u16, vp, vp, vp, sz, vp, vp, vp]
     lib.jea_static_scratch_needed.argtypes = [sz, u16, u16]
     lib.jea_static_scratch_needed.restype = sz
@@ -492,6 +497,42 @@ class Context:
         self._check(self.lib.jea_encode_host(self.handle, rgb.ctypes.data, w, h, lum.ctypes.data, chrom.ctypes.data,
                                              out.ctypes.data, capacity, ctypes.byref(n)))
         return out[: n.value].tobytes()
+
+    def host_array(self, n_bytes):
+        """uint8 numpy array of n_bytes in pinned host memory (jea_host_malloc), which the GPU reads and writes directly;
+        free with host_free(array) when done."""
+        p = ctypes.c_void_p()
+        self._check(self.lib.jea_host_malloc(self.handle, int(n_bytes), ctypes.byref(p)))
+        a = np.ctypeslib.as_array((ctypes.c_uint8 * int(n_bytes)).from_address(p.value))
+        self._host_arrays = getattr(self, "_host_arrays", {})
+        self._host_arrays[a.ctypes.data] = p
+        return a
+
+    def host_free(self, array):
+        p = self._host_arrays.pop(array.ctypes.data)
+        self._check(self.lib.jea_host_free(self.handle, p))
+
+    def encode_host_batch(self, rgb, lum, chrom, out=None, capacity=None):
+        """rgb: [n, h, w, 3] uint8 in host memory (pageable or pinned) -> (out array, offsets, sizes)."""
+        n, h, w = rgb.shape[:3]
+        assert rgb.flags.c_contiguous and rgb.dtype == np.uint8
+        if out is None:
+            out = np.zeros(capacity if capacity is not None else n * ((max_jpeg_bytes(w, h) + 63) // 64 * 64), np.uint8)
+        offsets, sizes = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        self._check(self.lib.jea_encode_host_batch(self.handle, rgb.ctypes.data, n, w, h, lum.ctypes.data, chrom.ctypes.data,
+                                                   out.ctypes.data, out.size, offsets.ctypes.data, sizes.ctypes.data))
+        return out, offsets, sizes
+
+    def decode_host_batch(self, jpeg, offsets, sizes, w, h, lum, chrom, out=None):
+        """jpeg: uint8 array in host memory holding the files -> [n, h, w, 3] uint8."""
+        n = len(offsets)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        sizes = np.ascontiguousarray(sizes, np.uint64)
+        if out is None:
+            out = np.zeros(n * h * w * 3, np.uint8)
+        self._check(self.lib.jea_decode_host_batch(self.handle, jpeg.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, n, w, h,
+                                                   lum.ctypes.data, chrom.ctypes.data, out.ctypes.data))
+        return out.reshape(-1)[: n * h * w * 3].reshape(n, h, w, 3)
 
     def decode_batch(self, d_jpeg, offsets, sizes, w, h, lum, chrom):
         n = len(offsets)

@@ -66,6 +66,19 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// One of the two staging slots of the host-to-host batch entry points: while the kernels work on one slot's piece, the
+// next piece travels to the other slot and the piece before travels back.
+struct PipeSlot {
+    DeviceBuffer d_in, d_out, d_meta;
+    void* pin_in = nullptr;
+    size_t pin_in_bytes = 0;
+    void* pin_out = nullptr;
+    size_t pin_out_bytes = 0;
+    void* pin_meta = nullptr;
+    size_t pin_meta_bytes = 0;
+    hipEvent_t h2d = nullptr, work = nullptr, d2h = nullptr;
+};
+
 struct jea_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -98,6 +111,9 @@ struct jea_ctx {
     // jea_encode_batch_async on large batches: a second stream and the events that tie it to `stream`
     hipStream_t lane_stream = nullptr;
     hipEvent_t lane_fork = nullptr, lane_join = nullptr, lane_offsets[2] = {nullptr, nullptr};
+    // jea_encode_host_batch / jea_decode_host_batch: copy streams and staging
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    PipeSlot pipe[2];
     void* pinned = nullptr;   // host memory the GPU reads and writes: decode bookkeeping
     size_t pinned_bytes = 0;
     size_t stream_len = 0;
@@ -181,6 +197,8 @@ int ensure_pin_io(jea_ctx* ctx, size_t bytes) {
 }
 
 // memcpy by a few threads: one thread moves some 10 GB/s, a PCIe link five times that
+// (four threads reach 75 GB/s between pageable and pinned memory on the hosts measured, eight little more, sixteen less:
+// tools/host_copy_rates.hip)
 void parallel_memcpy(void* dst, const void* src, size_t bytes) {
     constexpr size_t kThreads = 4, kMinPerThread = 1u << 20;
     if (bytes < 2 * kMinPerThread) {
@@ -539,6 +557,20 @@ void jea_destroy(jea_ctx* ctx) {
                             &ctx->huff_hist, &ctx->huff_tables, &ctx->huff_spec, &ctx->step_tables,
                             &ctx->ctx_vals, &ctx->tile_ff8, &ctx->group_flags})
         free_buffer(*b);
+    for (hipStream_t st : {ctx->copy_in, ctx->copy_out})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (PipeSlot& sl : ctx->pipe) {
+        free_buffer(sl.d_in);
+        free_buffer(sl.d_out);
+        free_buffer(sl.d_meta);
+        for (void* h : {sl.pin_in, sl.pin_out, sl.pin_meta})
+            if (h) (void)hipHostFree(h);
+        for (hipEvent_t e : {sl.h2d, sl.work, sl.d2h})
+            if (e) (void)hipEventDestroy(e);
+    }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
     for (hipEvent_t e : ctx->piece_done)
@@ -1627,6 +1659,240 @@ int jea_decode_host(jea_ctx* ctx, const uint8_t* h_jpeg, size_t len, uint16_t wi
                           (uint8_t*)ctx->stage_in.ptr);
     if (rc) return rc;
     return download_pipelined(ctx, h_rgb, ctx->stage_in.ptr, out_bytes);
+}
+
+// ---- batches in host memory ----------------------------------------------------
+//
+// The caller of the reference holds bitmaps and files in host memory (examples/encode-decode.cpp:104-118).  A batch
+// of them goes through the GPU in pieces of about 32 MB of pixels on two staging slots, so that three things overlap:
+// the host copies the next piece into pinned memory and the copy engine moves it over the link (one stream), the
+// kernels work on the current piece (the context's stream), and the piece before travels back (another stream)
+// and is copied to the caller's memory.  Caller memory that is pinned already (jea_host_malloc) skips the host copies.
+// The streams are ordered by events that are always recorded before they are waited for, all at one priority.
+
+namespace {
+
+int ensure_host(jea_ctx* ctx, void*& ptr, size_t& have, size_t want) {
+    if (want <= have) return JEA_OK;
+    if (ptr) JEA_HIP(ctx, hipHostFree(ptr));
+    ptr = nullptr;
+    have = 0;
+    const size_t bytes = want + want / 8 + 4096;
+    JEA_HIP(ctx, hipHostMalloc(&ptr, bytes, hipHostMallocDefault));
+    have = bytes;
+    return JEA_OK;
+}
+
+int prepare_pipe(jea_ctx* ctx) {
+    if (!ctx->copy_in) JEA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+    if (!ctx->copy_out) JEA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+    for (PipeSlot& sl : ctx->pipe)
+        for (hipEvent_t* e : {&sl.h2d, &sl.work, &sl.d2h})
+            if (!*e) JEA_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return JEA_OK;
+}
+
+// Everything the pipeline has in flight, before its buffers change size or the call returns.
+int drain_pipe(jea_ctx* ctx) {
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->copy_in));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JEA_HIP(ctx, hipStreamSynchronize(ctx->copy_out));
+    return JEA_OK;
+}
+
+// Memory the GPU can reach directly (hipHostMalloc, jea_host_malloc)?
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+size_t images_per_piece(size_t image_bytes, size_t n_images) {
+    size_t k = ((size_t)32 << 20) / image_bytes;
+    if (k < 1) k = 1;
+    if (k > n_images) k = n_images;
+    if (k > 4096) k = 4096;
+    return k;
+}
+
+}  // namespace
+
+int jea_host_malloc(jea_ctx* ctx, size_t bytes, void** h_ptr) {
+    if (!ctx || !h_ptr || bytes == 0) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    JEA_HIP(ctx, hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    return JEA_OK;
+}
+
+int jea_host_free(jea_ctx* ctx, void* h_ptr) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    JEA_HIP(ctx, hipHostFree(h_ptr));
+    return JEA_OK;
+}
+
+int jea_encode_host_batch(jea_ctx* ctx, const uint8_t* h_rgb, size_t n_images, uint16_t width, uint16_t height,
+                          const uint16_t lum_q[64], const uint16_t chr_q[64], uint8_t* h_out, size_t out_capacity,
+                          uint64_t* h_offsets, uint64_t* h_sizes) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_rgb || !h_out || !h_offsets || !h_sizes || n_images == 0 || !valid_dims(width, height) ||
+        !tables_ok(lum_q, chr_q) || out_capacity < JEA_HEADER_BYTES + 3)
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_encode_host_batch: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = prepare_pipe(ctx))) return rc;
+    const size_t image_bytes = (size_t)3 * width * height;
+    const size_t k = images_per_piece(image_bytes, n_images);
+    const size_t n_pieces = (n_images + k - 1) / k;
+    const size_t worst = k * ((jea_max_jpeg_bytes(width, height) + 63) / 64 * 64);
+    const size_t piece_cap = worst < out_capacity ? worst : out_capacity;   // no piece can need more than the caller has room for
+    const size_t meta_bytes = (2 * k + 1) * sizeof(uint64_t);               // offsets | sizes | status
+    const bool in_pinned = is_pinned(h_rgb), out_pinned = is_pinned(h_out);
+    if ((rc = drain_pipe(ctx))) return rc;
+    for (PipeSlot& sl : ctx->pipe) {
+        if ((rc = ensure(ctx, sl.d_in, k * image_bytes))) return rc;
+        if ((rc = ensure(ctx, sl.d_out, piece_cap))) return rc;
+        if ((rc = ensure(ctx, sl.d_meta, meta_bytes))) return rc;
+        if (!in_pinned && (rc = ensure_host(ctx, sl.pin_in, sl.pin_in_bytes, k * image_bytes))) return rc;
+        if ((rc = ensure_host(ctx, sl.pin_meta, sl.pin_meta_bytes, meta_bytes))) return rc;
+    }
+    // (the context's own scratch grows inside the first piece's encode call, before anything else is in flight)
+    auto images_of = [&](size_t p) { return p + 1 < n_pieces ? k : n_images - p * k; };
+    uint64_t out_at = 0;      // where the next piece's files start in h_out (a multiple of 64)
+    struct Placed { uint64_t at, bytes; };
+    Placed placed[2] = {{0, 0}, {0, 0}};
+    int result = JEA_OK;
+    // three stages, one piece apart: [A] piece p goes in and is encoded, [B] the sizes of piece p-1 arrive and its
+    // files start back, [C] the files of piece p-2 reach the caller's memory
+    for (size_t p = 0; p < n_pieces + 2 && result == JEA_OK; ++p) {
+        if (p < n_pieces) {
+            PipeSlot& sl = ctx->pipe[p & 1];
+            const size_t n = images_of(p), bytes = n * image_bytes;
+            const uint8_t* src = h_rgb + p * k * image_bytes;
+            // the slot's staging memory is free once the copy of piece p-2 has left it, its device input once
+            // that piece has been encoded
+            JEA_HIP(ctx, hipEventSynchronize(sl.h2d));
+            JEA_HIP(ctx, hipStreamWaitEvent(ctx->copy_in, sl.work, 0));
+            if (!in_pinned) {
+                parallel_memcpy(sl.pin_in, src, bytes);
+                src = (const uint8_t*)sl.pin_in;
+            }
+            JEA_HIP(ctx, hipMemcpyAsync(sl.d_in.ptr, src, bytes, hipMemcpyHostToDevice, ctx->copy_in));
+            JEA_HIP(ctx, hipEventRecord(sl.h2d, ctx->copy_in));
+            JEA_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.h2d, 0));
+            JEA_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.d2h, 0));   // the files of piece p-2 have left d_out
+            uint64_t* m = (uint64_t*)sl.d_meta.ptr;
+            rc = jea_encode_batch_async(ctx, (const uint8_t*)sl.d_in.ptr, n, width, height, lum_q, chr_q,
+                                        (uint8_t*)sl.d_out.ptr, piece_cap, m, m + k, (int32_t*)(m + 2 * k));
+            if (rc) { result = rc; break; }
+            JEA_HIP(ctx, hipMemcpyAsync(sl.pin_meta, sl.d_meta.ptr, meta_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            JEA_HIP(ctx, hipEventRecord(sl.work, ctx->stream));
+        }
+        if (p >= 1 && p - 1 < n_pieces) {
+            const size_t q = p - 1;
+            PipeSlot& sl = ctx->pipe[q & 1];
+            const size_t n = images_of(q);
+            JEA_HIP(ctx, hipEventSynchronize(sl.work));
+            const uint64_t* m = (const uint64_t*)sl.pin_meta;
+            const int32_t st = (int32_t)m[2 * k];
+            if (st != 0) { result = report_status(ctx, st, "jea_encode_host_batch"); break; }
+            const uint64_t bytes = m[n - 1] + m[k + n - 1];       // files lie back to back from offset 0 at 64-byte steps
+            if (out_at + bytes > out_capacity) {
+                result = fail(ctx, JEA_ERR_CAPACITY, "jea_encode_host_batch: output capacity too small");
+                break;
+            }
+            for (size_t i = 0; i < n; ++i) {
+                h_offsets[q * k + i] = out_at + m[i];
+                h_sizes[q * k + i] = m[k + i];
+            }
+            uint8_t* dst = h_out + out_at;
+            if (!out_pinned) {
+                // the slot's pinned output is free: piece q-2 was copied out of it in stage C of the round before
+                if ((rc = ensure_host(ctx, sl.pin_out, sl.pin_out_bytes, bytes))) { result = rc; break; }
+                dst = (uint8_t*)sl.pin_out;
+            }
+            JEA_HIP(ctx, hipMemcpyAsync(dst, sl.d_out.ptr, bytes, hipMemcpyDeviceToHost, ctx->copy_out));
+            JEA_HIP(ctx, hipEventRecord(sl.d2h, ctx->copy_out));
+            placed[q & 1] = Placed{out_at, bytes};
+            out_at = (out_at + bytes + 63) / 64 * 64;
+        }
+        if (p >= 2) {
+            PipeSlot& sl = ctx->pipe[p & 1];
+            JEA_HIP(ctx, hipEventSynchronize(sl.d2h));
+            if (!out_pinned) parallel_memcpy(h_out + placed[p & 1].at, sl.pin_out, placed[p & 1].bytes);
+        }
+    }
+    const int drained = drain_pipe(ctx);
+    return result != JEA_OK ? result : drained;
+}
+
+int jea_decode_host_batch(jea_ctx* ctx, const uint8_t* h_jpeg, const uint64_t* h_offsets, const uint64_t* h_sizes,
+                          size_t n_images, uint16_t width, uint16_t height, const uint16_t lum_q[64],
+                          const uint16_t chr_q[64], uint8_t* h_rgb) {
+    if (!ctx) return JEA_ERR_INVALID_ARG;
+    if (!h_jpeg || !h_offsets || !h_sizes || !h_rgb || n_images == 0 || !valid_dims(width, height) || !tables_ok(lum_q, chr_q))
+        return fail(ctx, JEA_ERR_INVALID_ARG, "jea_decode_host_batch: invalid argument");
+    JEA_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = prepare_pipe(ctx))) return rc;
+    // the headers are judged first, as the reference would (encoder.cpp:48)
+    for (size_t i = 0; i < n_images; ++i) {
+        const char* msg = nullptr;
+        if (jea_check_header(h_jpeg + h_offsets[i], (size_t)h_sizes[i], nullptr, nullptr, &msg) != JEA_OK)
+            return fail(ctx, JEA_ERR_BAD_HEADER, msg);
+    }
+    const size_t image_bytes = (size_t)3 * width * height;
+    const size_t k = images_per_piece(image_bytes, n_images);
+    const size_t n_pieces = (n_images + k - 1) / k;
+    const bool out_pinned = is_pinned(h_rgb);
+    auto images_of = [&](size_t p) { return p + 1 < n_pieces ? k : n_images - p * k; };
+    size_t max_files = 0;   // bytes of the files of the largest piece, each rounded up to 64
+    for (size_t p = 0; p < n_pieces; ++p) {
+        size_t total = 0;
+        for (size_t i = 0; i < images_of(p); ++i) total += ((size_t)h_sizes[p * k + i] + 63) / 64 * 64;
+        if (total > max_files) max_files = total;
+    }
+    if ((rc = drain_pipe(ctx))) return rc;
+    for (PipeSlot& sl : ctx->pipe) {
+        if ((rc = ensure(ctx, sl.d_in, max_files))) return rc;
+        if ((rc = ensure(ctx, sl.d_out, k * image_bytes))) return rc;
+        if ((rc = ensure_host(ctx, sl.pin_in, sl.pin_in_bytes, max_files))) return rc;
+        if (!out_pinned && (rc = ensure_host(ctx, sl.pin_out, sl.pin_out_bytes, k * image_bytes))) return rc;
+    }
+    std::vector<uint64_t> offs(k), sizes(k);
+    int result = JEA_OK;
+    // per round: the pixels of piece p-2 reach the caller's memory, then piece p's files go in and are decoded (the
+    // decode waits for the GPU itself), then its pixels start back -- while the pixels of piece p-1 are still on the link
+    for (size_t p = 0; p < n_pieces + 2 && result == JEA_OK; ++p) {
+        if (p >= 2) {
+            PipeSlot& sl = ctx->pipe[p & 1];
+            JEA_HIP(ctx, hipEventSynchronize(sl.d2h));
+            if (!out_pinned) parallel_memcpy(h_rgb + (p - 2) * k * image_bytes, sl.pin_out, images_of(p - 2) * image_bytes);
+        }
+        if (p < n_pieces) {
+            PipeSlot& sl = ctx->pipe[p & 1];
+            const size_t n = images_of(p);
+            size_t at = 0;
+            for (size_t i = 0; i < n; ++i) {
+                offs[i] = at;
+                sizes[i] = h_sizes[p * k + i];
+                std::memcpy((uint8_t*)sl.pin_in + at, h_jpeg + h_offsets[p * k + i], (size_t)sizes[i]);
+                at += ((size_t)sizes[i] + 63) / 64 * 64;
+            }
+            JEA_HIP(ctx, hipMemcpyAsync(sl.d_in.ptr, sl.pin_in, at, hipMemcpyHostToDevice, ctx->stream));
+            rc = jea_decode_batch(ctx, (const uint8_t*)sl.d_in.ptr, offs.data(), sizes.data(), n, width, height, lum_q, chr_q,
+                                  (uint8_t*)sl.d_out.ptr);
+            if (rc) { result = rc; break; }
+            uint8_t* dst = out_pinned ? h_rgb + p * k * image_bytes : (uint8_t*)sl.pin_out;
+            JEA_HIP(ctx, hipMemcpyAsync(dst, sl.d_out.ptr, n * image_bytes, hipMemcpyDeviceToHost, ctx->copy_out));
+            JEA_HIP(ctx, hipEventRecord(sl.d2h, ctx->copy_out));
+        }
+    }
+    const int drained = drain_pipe(ctx);
+    return result != JEA_OK ? result : drained;
 }
 
 // ---- component-level entry points ---------------------------------------------

@@ -949,3 +949,58 @@ def test_two_stream_batches_on_three_contexts_at_once(jea, po):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("w,h,n,quality,pinned", [(200, 136, 7, 75, False), (1920, 1080, 13, 90, False), (3840, 2160, 5, 75, True),
+                                                  (640, 480, 130, 50, True)])
+def test_host_batches_through_the_staging_pipeline(ctx, po, jea, w, h, n, quality, pinned):
+    """Batches held in host memory: pieces of about 32 MB travel in, are coded and travel back on two staging slots.
+    Files, offsets and sizes are those of the device-resident batch call; the decoded bitmaps are the oracle's.
+    Pageable caller memory and memory from jea_host_malloc (which the GPU reads and writes directly)."""
+    b = jea.binding
+    lum, chrom = b.quant_tables(quality)
+    distinct = [po.gen_image(w, h, 1 if i == 2 else 0, 5000 + i) for i in range(4)]
+    want_files = [po.encode(im, quality) for im in distinct]
+    want_rgb = [po.decode(f, w, h, quality) for f in want_files]
+    pick = [(3 * i + i // 5) % 4 for i in range(n)]
+    cap = sum((len(want_files[k]) + 63) // 64 * 64 for k in pick)
+    held = []
+    try:
+        if pinned:
+            rgb = ctx.host_array(n * h * w * 3).reshape(n, h, w, 3)
+            out = ctx.host_array(cap)
+            held = [rgb, out]
+        else:
+            rgb, out = np.zeros((n, h, w, 3), np.uint8), np.zeros(cap, np.uint8)
+        for i, k in enumerate(pick):
+            rgb[i] = distinct[k]
+        out[:] = 0xA5
+        _, off, size = ctx.encode_host_batch(rgb, lum, chrom, out=out)
+        at = 0
+        for i, k in enumerate(pick):
+            assert int(off[i]) == at and int(size[i]) == len(want_files[k]), i
+            assert out[at: at + len(want_files[k])].tobytes() == want_files[k], i
+            at = (at + len(want_files[k]) + 63) // 64 * 64
+        # one byte less than the files need
+        with pytest.raises(b.JeaError) as e:
+            ctx.encode_host_batch(rgb, lum, chrom, out=out[: int(off[-1]) + int(size[-1]) - 1])
+        assert e.value.code == 3
+        # and back: the files from where they lie, in another order
+        order = list(reversed(range(n)))
+        if pinned:
+            back = ctx.host_array(n * h * w * 3)
+            held.append(back)
+        else:
+            back = np.zeros(n * h * w * 3, np.uint8)
+        got = ctx.decode_host_batch(out, [off[i] for i in order], [size[i] for i in order], w, h, lum, chrom, out=back)
+        for j, i in enumerate(order):
+            assert np.array_equal(got[j], want_rgb[pick[i]]), (j, i)
+        # a damaged file in the middle of the batch: the reference's message, whatever piece it is in
+        bad = out.copy()
+        bad[int(off[n // 2]) + 3] ^= 0x40
+        with pytest.raises(b.JeaError) as e:
+            ctx.decode_host_batch(bad, off, size, w, h, lum, chrom, out=back)
+        assert e.value.code == 5 and "APP-0" in e.value.message
+    finally:
+        for a in held:
+            ctx.host_free(a.reshape(-1))
