@@ -228,3 +228,51 @@ def test_decode_batch_whose_block_records_leave_in_fours_at_every_alignment(ctx,
     rgb = ctx.decode_batch(d_jpeg, offs, sizes, w, h, lum, chrom).view(n, h, w, 3)
     wrong = [i for i in range(n) if not torch.equal(rgb[i], want[kind[i]].view(h, w, 3))]
     assert not wrong, (len(wrong), wrong[:8])
+
+
+def test_image_beyond_the_row_lane_kernels_range(jea, po):
+    """32768 x 23040 (755 MPix, 2.26 GB of pixels): with more than 4 GiB / 384 MCUs the whole image leaves the
+    row-lane forward kernel for the general one, while stripes of it still take the row-lane kernel -- the two routes
+    must write the same file.  The file is decoded again and sampled MCU rows are compared with the oracle, run on
+    those rows alone (a block's pixels depend on its own coefficients only)."""
+    import torch
+
+    stripes = importlib.import_module("jpeg-encoder_amd.stripes")
+    w, h, quality = 32768, 23040, 75
+    assert (w // 8) * (h // 8) * 384 >= 1 << 32
+    lum, chrom = jea.binding.quant_tables(quality)
+    tile = po.gen_image(4096, 2880, 0, 77)
+    tile[1000:1400, 500:3000] = po.gen_image(2500, 400, 1, 78)      # a band of noise in every tile
+    rgb = np.tile(tile, (8, 8, 1))
+    rgb[::2880, :, 0] ^= 0x55                                        # and what makes the tiles' first rows differ
+    assert rgb.shape == (h, w, 3)
+    rows = stripes.stripe_rows(h, 4)
+    ctxs = [jea.Context(0) for _ in rows]
+    try:
+        c = ctxs[0]
+        d_rgb = c.to_device(rgb.reshape(-1))
+        cap = 1 << 30
+        out, off, size = c.encode_batch(d_rgb, 1, w, h, lum, chrom, capacity=cap)
+        whole = out[: int(size[0])].cpu().numpy()
+        del out
+        striped = [stripes.DeviceStripe(x, d_rgb[y0 * w * 3: y1 * w * 3], w, y1 - y0, lum, chrom, x.empty(cap // 2, torch.uint8))
+                   for x, (y0, y1) in zip(ctxs, rows)]
+        parts = stripes.encode_in_process_on_device(striped, w, h)
+        assert len(parts) == whole.size and parts == whole.tobytes()
+        del striped, parts, d_rgb
+        torch.cuda.empty_cache()
+        d_jpeg = c.to_device(whole)
+        dec = c.decode_batch(d_jpeg, [0], [whole.size], w, h, lum, chrom).cpu().numpy().reshape(h, w, 3)
+    finally:
+        for x in ctxs:
+            x.close()
+    rng = np.random.RandomState(5)
+    sample = sorted(set([0, h // 8 - 1] + list(rng.randint(0, h // 8, 200))))
+
+    def band_ok(r):
+        band = np.ascontiguousarray(rgb[8 * r: 8 * r + 8])
+        return np.array_equal(dec[8 * r: 8 * r + 8], po.decode(po.encode(band, quality), w, 8, quality))
+
+    with concurrent.futures.ThreadPoolExecutor(THREADS) as tp:
+        ok = list(tp.map(band_ok, sample))
+    assert all(ok), [r for r, good in zip(sample, ok) if not good][:10]
