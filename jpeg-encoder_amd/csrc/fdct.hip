@@ -326,7 +326,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool kPlanar>
+template <bool kPlanar, bool kStrided = false>
 __global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_rows_kernel(
     const uint8_t* __restrict__ rgb, int width, int height, int blocks_w, uint32_t n_mcu, size_t image_bytes, QuantTables q,
     int16_t* __restrict__ coefs, int32_t* __restrict__ status_to_clear, uint8_t* __restrict__ chunk_masks, ComponentMode mode,
@@ -340,8 +340,11 @@ __global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_row
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = (uint32_t)tid & 63u, m = lane >> 3, s = lane & 7u;
     const uint32_t n_units = (n_mcu + 7u) >> 3;
-    uint32_t unit = ((uint32_t)blockIdx.x * kRowWaves + (uint32_t)wave) * units_per_wave;
-    const uint32_t unit_end = unit + units_per_wave < n_units ? unit + units_per_wave : n_units;
+    // kStrided (experiment): as many waves as the GPU holds at once, wave w takes units w, w + waves, w + 2 waves, ...
+    const uint32_t unit_step = kStrided ? gridDim.x * kRowWaves : 1u;
+    uint32_t unit = kStrided ? (uint32_t)blockIdx.x * kRowWaves + (uint32_t)wave
+                             : ((uint32_t)blockIdx.x * kRowWaves + (uint32_t)wave) * units_per_wave;
+    const uint32_t unit_end = kStrided ? n_units : (unit + units_per_wave < n_units ? unit + units_per_wave : n_units);
     const bool has_work = unit < unit_end;   // per wave; false only in the last workgroup of a picture
 
     // MCU of this lane in the first unit; later units are 8 MCUs further each.  Width and height are multiples
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_row
     const uint32_t channel_step = kPlanar ? plane_bytes : 128u;
     uint32_t out_off = kPlanar ? s * 3u * plane_bytes + mcu * 16u : mcu * 384u + 16u * s, mask_off = mcu * 3u;
 
-    for (; unit < unit_end; ++unit) {
+    for (; unit < unit_end; unit += unit_step) {
         const bool valid = mcu < n_mcu;
         const uint32_t d[6] = {cur[0].x, cur[0].y, cur[1].x, cur[1].y, cur[2].x, cur[2].y};
         float px[24];
@@ -429,7 +432,18 @@ __global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_row
             asm volatile("" : "+v"(px[i]));   // from here on the floats are all there is (no second, integer copy of the bytes)
         }
         // the next unit's pixels are on their way while this one is worked on
-        if (unit + 1 < unit_end) {
+        if (kStrided) {
+            if (unit + unit_step < unit_end) {
+                const uint32_t next = mcu + 8u * unit_step, next_in = next < n_mcu ? next : n_mcu - 1u;
+                uint32_t by = (uint32_t)((float)next_in * __builtin_amdgcn_rcpf((float)blocks_w));
+                int32_t bxs = (int32_t)next_in - (int32_t)(by * (uint32_t)blocks_w);
+                by = bxs < 0 ? by - 1u : (bxs >= blocks_w ? by + 1u : by);
+                bxs = bxs < 0 ? bxs + blocks_w : (bxs >= blocks_w ? bxs - blocks_w : bxs);
+                src = rgb + (size_t)blockIdx.y * image_bytes + ((size_t)by * 8 + s) * row_bytes + (size_t)bxs * 24;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cur[i] = reinterpret_cast<const uint2*>(src)[i];
+            }
+        } else if (unit + 1 < unit_end) {
             bx += 8u;
             const bool wraps = bx >= (uint32_t)blocks_w;
             bx -= wraps ? (uint32_t)blocks_w : 0u;
@@ -505,9 +519,9 @@ __global__ __launch_bounds__(kRowThreads, JEA_ROW_MIN_WAVES) void fdct_quant_row
                     (mask_image + ch)[mask_off] = (uint8_t)((m < 4 ? (uint32_t)nz : (uint32_t)(nz >> 32)) >> (8 * (m & 3u)));
             }
         }
-        mcu += 8u;
-        out_off += kPlanar ? 8u * 16u : 8u * 384u;
-        mask_off += 8u * 3u;
+        mcu += 8u * unit_step;
+        out_off += (kPlanar ? 8u * 16u : 8u * 384u) * unit_step;
+        mask_off += 8u * 3u * unit_step;
     }
 }
 
@@ -1249,6 +1263,13 @@ void launch_fdct_quant(hipStream_t s, const uint8_t* d_rgb, size_t n_images, int
 #endif
         const dim3 grid_rows((unsigned)((units + (uint64_t)kRowWaves * best_k - 1) / ((uint64_t)kRowWaves * best_k)),
                              (unsigned)n_images);
+#ifdef JEA_K1_STRIDED_WAVES   // experiments: a launch of that many waves, each striding over the units
+        if (planar && n_images == 1) {
+            fdct_quant_rows_kernel<true, true><<<dim3(JEA_K1_STRIDED_WAVES / kRowWaves, 1), kRowThreads, kRowDynLds, s>>>(
+                d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs, d_status_to_clear, d_chunk_masks, mode, 1);
+            return;
+        }
+#endif
         if (planar)
             fdct_quant_rows_kernel<true><<<grid_rows, kRowThreads, kRowDynLds, s>>>(d_rgb, width, height, bw, n_mcu, image_bytes, q, d_coefs,
                                                                            d_status_to_clear, d_chunk_masks, mode, best_k);

@@ -157,22 +157,26 @@ struct SlotSink {
     uint32_t* slot;  // first word of the block's string; consecutive words are `stride` apart
     uint32_t stride = kSlotStride;
     uint32_t bits = 0;
-    uint64_t acc = 0;
-    uint32_t nacc = 0;
+    uint32_t acc = 0;    // the word being filled, MSB first
+    uint32_t nacc = 0;   // bits of it in use, 0..31
+    // 32-bit arithmetic throughout: a 64-bit accumulator costs a 64-bit shift per symbol, which issues at a quarter
+    // of the rate of the 32-bit ones
     __device__ __forceinline__ void put(uint32_t v, uint32_t n) {
-        acc |= (uint64_t)v << (64u - nacc - n);
+        const uint32_t t = v << (32u - n);       // the n bits at the top of a word (n is 1..27)
+        acc |= t >> nacc;
+        const uint32_t used = nacc;
         nacc += n;
         bits += n;
         if (nacc >= 32) {
-            *slot = (uint32_t)(acc >> 32);
+            *slot = acc;
             slot += stride;
-            acc <<= 32;
+            acc = __builtin_amdgcn_alignbit(t, 0u, used);   // what did not fit: t << (32 - used); nothing when used == 0
             nacc -= 32;
         }
     }
     __device__ __forceinline__ void symbol(bool, uint32_t) {}
     __device__ __forceinline__ void finish() {
-        if (nacc > 0) *slot = (uint32_t)(acc >> 32);
+        if (nacc > 0) *slot = acc;
     }
 };
 
