@@ -194,8 +194,11 @@ def region_stats(regions):
 
 
 def pmc_profile(name):
-    path = os.path.join(ROOT, "profiles", name)
-    return json.load(open(path)) if os.path.exists(path) else None
+    """profiles/rNN_<name> of the latest round that has one (counter passes are taken with tools/refresh_profiles.sh)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)))
+    return json.load(open(found[-1])) if found else None
 
 
 def cpu_encode_baseline(po, images, quality, n_single, threads):
@@ -470,7 +473,7 @@ def config_c2(job):
     roofline, one_ms = forward_kernel_roofline(job, ctx, groups, pool.whole, W, H, lum, chrom, batch, args.marginal_images)
     # HBM bytes and instruction counts per launch from the PMC counters, collected in separate rocprofv3 passes
     # over this same command (tools/refresh_profiles.sh); valid for the workload they were taken on
-    pmc = pmc_profile("r02_k1_issue.json") if (batch == 1 and args.mode == 0) else None
+    pmc = pmc_profile("k1_issue.json") if (batch == 1 and args.mode == 0) else None
     roofline["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
     roofline["bound"] = "valu"
     roofline["bound_note"] = ("vector-instruction issue, not memory: the reference's operation order (every product and "
@@ -645,7 +648,7 @@ def config_c5(job, steps=None, warmup=None, with_cpu=True):
     px = n * FW * FH
     # HBM bytes of the inverse transform's kernels from the PMC passes over this configuration (tools/refresh_profiles.sh);
     # valid for the full 1024-frame call on one GPU
-    pmc5 = pmc_profile("r02_pmc_traffic_c5.json") if (job.world == 1 and n == 1024) else None
+    pmc5 = pmc_profile("pmc_traffic_c5.json") if (job.world == 1 and n == 1024) else None
     inverse_traffic = None
     if pmc5:
         inverse_traffic = sum(pmc5["kernels"].get(k, {}).get("hbm_bytes_per_launch", 0) for k in ("idct_sparse_kernel", "idct_dequant_kernel"))
