@@ -211,18 +211,26 @@ def collect_segments(stripe, sizes, rank, world, dist, on_device=True, dst=0):
     if not on_device:
         mine = mine.cpu()
     if rank != dst:
-        dist.send(mine, dst=dst)
+        if on_device:   # RCCL: point-to-point operations go out as one group
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst)]):
+                req.wait()
+        else:
+            dist.send(mine, dst=dst)
         return None
     file = torch.empty(sum(host_sizes), dtype=torch.uint8, device=mine.device)
     at = 0
-    pending = []
+    receives = []
     for r in range(world):
         part = file[at: at + host_sizes[r]]
         if r == dst:
             part.copy_(mine)
         else:
-            pending.append(dist.irecv(part, src=r))
+            receives.append((part, r))
         at += host_sizes[r]
+    if on_device:
+        pending = dist.batch_isend_irecv([dist.P2POp(dist.irecv, part, r) for part, r in receives])
+    else:
+        pending = [dist.irecv(part, src=r) for part, r in receives]
     for p in pending:
         p.wait()
     return file

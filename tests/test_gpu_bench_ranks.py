@@ -37,3 +37,17 @@ def test_bench_gpus_2_shards_a_batch_by_image():
                   JEA_DIST_BACKEND="gloo")
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
     assert line["config"]["workload"].startswith("batch of 6 1920x1080 frames") and "3 per rank" in line["config"]["workload"]
+
+
+def test_bench_c4_over_rccl_with_one_rank():
+    """The RCCL calls of the stripe protocol (all-gathers of bytes from device memory to device memory, issued under the
+    context's stream) on the one GPU there is: a process group of a single rank over the `nccl` backend."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    line = _bench("--gpus", "1", "--config", "c4", "--c4-size", "2048", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                  JEA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["comm_backend"] == "nccl (RCCL)"
+    assert line["config"]["file_checked_against"] == "oracle, byte for byte"
