@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t
                                                                 uint32_t* __restrict__ tile_bits,
                                                                 uint4* __restrict__ tile_ff8,
                                                                 int32_t* __restrict__ status, uint32_t tables_per_image) {
-    __shared__ HuffLds h;
+    __shared__ HuffTop h;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t count[8];
     __shared__ uint32_t lens[kEntThreads];
@@ -503,19 +503,20 @@ __global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t
             prev_dc = (b >= 3) ? (int)p[-192] : 0;
         }
     }
-    load_huff<kEntThreads>(h, huff + (tables_per_image ? blockIdx.y : 0u));
+    load_huff_top<kEntThreads>(h, huff + (tables_per_image ? blockIdx.y : 0u));
     if (threadIdx.x < 8) count[threadIdx.x] = 0;
     __syncthreads();
 
-    uint32_t* const slot = slots + ((size_t)img * n_tiles + tile) * kSlotWords * kSlotStride + threadIdx.x;
+    uint32_t* const tile_slots = slots + ((size_t)img * n_tiles + tile) * kSlotWords * kSlotStride;
+    uint32_t* const slot = tile_slots + threadIdx.x;
     uint32_t my_len = 0;
     if (has_block) {
         const int cls = mode.is_lum((uint32_t)ch) ? 0 : 1;   // Huffman table class (encoder.cpp:25)
-        SlotSink sink;
-        sink.slot = slot;
-        if (!encode_block(blk, prev_dc, h.dc[cls], h.ac[cls], sink)) atomicExch(status, JEA_ERR_RANGE);
+        TopSink sink(tile_slots, threadIdx.x);
+        // the chunk-planar layout is the library's own: coefficients from its quantiser
+        if (!encode_block_top<!kPlanar>(blk, prev_dc, h.dc[cls], h.ac[cls], sink)) atomicExch(status, JEA_ERR_RANGE);
         sink.finish();
-        my_len = sink.bits;
+        my_len = sink.bits();
         if (threadIdx.x < kTileBlocks) len16[(size_t)img * nbc + b] = (uint16_t)my_len;
     }
     lens[threadIdx.x] = my_len;

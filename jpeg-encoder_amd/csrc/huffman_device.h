@@ -180,6 +180,151 @@ struct SlotSink {
     }
 };
 
+// ---------------------------------------------------------------------------
+// The same symbols, for the kernel that writes every block's string (tile_bits_kernel), with the work per
+// coefficient cut down to what the vector ALU cannot be spared: that kernel is bound by instruction issue,
+// and two thirds of its instructions are this loop's body.
+//   * 8-byte table entries: .x = the code word at the top of a word with its length (at most 16) in the low five
+//     bits, .y = that length plus the number of amplitude bits that follow the code (which the symbol names: its
+//     low four bits, or the DC symbol itself).  One LDS read then gives the string's head in place, the shift
+//     that puts the amplitude bits behind it (shifts take the low five bits of their operand) and the string's length.
+//   * the size category of v from the leading bits of t = v - (v < 0), which the amplitude needs anyway:
+//     for v < 0, ~t = |v|, so t's leading ones are |v|'s leading zeros (entropy_encoder.cpp:745-765 takes the
+//     low bits of v or of v - 1).
+//   * the run is kept as the table address of (run, 0).
+// ---------------------------------------------------------------------------
+// An AC row holds a run's symbols by falling size category: (run, s) is entry 16 run + 16 - s, so that a value whose
+// t has f = 32 - s leading sign bits is found at 8 f bytes from a per-run address, one shift-and-add.  End-of-block
+// (0, 0) and the run of sixteen zeros (15, 0) sit at entries 16 and 256: the places of the size 16 no symbol has.
+struct HuffTop {
+    static constexpr uint32_t kAcEntries = 257, kEob = 16, kZrl = 256;
+    uint2 dc[2][12];
+    uint2 ac[2][kAcEntries + 1];
+};
+
+template <uint32_t kGroup>
+__device__ __forceinline__ void load_huff_top(HuffTop& h, const HuffTables* __restrict__ g) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
+    constexpr uint32_t kEntries = sizeof(HuffTables) / 4, kPerThread = (kEntries + kGroup - 1) / kGroup;
+    uint32_t v[kPerThread];
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; ++r) {
+        const uint32_t i = r * kGroup + threadIdx.x;
+        if (i < kEntries) v[r] = src[i];
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; ++r) {
+        const uint32_t i = r * kGroup + threadIdx.x;
+        if (i < kEntries) {
+            const uint32_t len = v[r] >> 16, code = v[r] & 0xffffu;
+            const uint32_t j = i - 24u, symbol = j & 255u;    // AC entries
+            const uint32_t amplitude_bits = i < 24u ? i % 12u : symbol & 15u;
+            const uint2 e = make_uint2((len ? code << (32u - len) : 0u) | len, len + amplitude_bits);
+            if (i < 24u) h.dc[i / 12u][i % 12u] = e;
+            else h.ac[j >> 8][(symbol >> 4) * 16u + 16u - (symbol & 15u)] = e;
+        }
+    }
+}
+
+// MSB-first writer into the block's slot that takes its strings at the top of a word.  The slot's words are
+// `kSlotStride` words apart; `base` is the same for the whole workgroup, so the stores take it from scalar registers
+// and a 32-bit offset per lane.
+struct TopSink {
+    uint8_t* base;
+    uint32_t offset;     // byte offset of the word being filled
+    uint32_t offset0;
+    uint32_t acc = 0;    // the word being filled
+    uint32_t nacc = 0;   // bits of it in use, 0..31
+    __device__ __forceinline__ TopSink(uint32_t* tile_slots, uint32_t column) : base(reinterpret_cast<uint8_t*>(tile_slots)), offset(4u * column), offset0(4u * column) {}
+    // the n bits at the top of t, n in 1..27, zeros below them
+    __device__ __forceinline__ void put_top(uint32_t t, uint32_t n) {
+        acc |= t >> nacc;
+        const uint32_t used = nacc;
+        nacc += n;
+        if (nacc >= 32) {
+            *reinterpret_cast<uint32_t*>(base + offset) = acc;
+            offset += 4u * kSlotStride;
+            acc = __builtin_amdgcn_alignbit(t, 0u, used);   // what did not fit: t << (32 - used); nothing when used == 0
+            nacc -= 32;
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (nacc > 0) *reinterpret_cast<uint32_t*>(base + offset) = acc;
+    }
+    __device__ __forceinline__ uint32_t bits() const { return (offset - offset0) / (4u * kSlotStride) * 32u + nacc; }
+};
+
+// encode_block for TopSink and HuffTop; the same strings, bit for bit.  Returns false when a value falls outside
+// the tables (its string is then some in-range value's).
+// kChecked = false: the AC values are known to lie within +-1023 and are not looked at again.  That holds for what the
+// library's own quantiser makes of 8-bit samples: an AC coefficient of the 8x8 transform of values in -128..127 is at
+// most 1020 in magnitude before the division (128 times the sum of the magnitudes of the basis function's 64 values
+// is 1024 for every one of them; half of the values meet 127 instead), and the divisors are at least 1.
+template <bool kChecked>
+__device__ __forceinline__ bool encode_block_top(const BlockRegs& blk, int prev_dc, const uint2* __restrict__ dc_tab,
+                                                 const uint2* __restrict__ ac_tab, TopSink& sink) {
+    bool ok = true;
+    {
+        const int diff = blk.at(0) - prev_dc;
+        const uint32_t amp = (uint32_t)(diff < 0 ? -diff : diff);
+        uint32_t s = bit_width(amp);
+        if (s > 11) { ok = false; s = 11; }
+        const uint2 e = dc_tab[s];
+        const uint32_t extra = (diff > 0 ? amp : ~amp) & ((1u << s) - 1u);
+        sink.put_top((e.x & ~31u) | __builtin_amdgcn_alignbit(extra, 0u, e.y), e.y);
+    }
+    // 32-bit LDS addresses, as numbers (a generic pointer is 64 bits wide, and so is every sum and comparison on it;
+    // as pointers the compiler splits them into base and offset again and adds the two at every read).
+    typedef __attribute__((address_space(3))) const uint8_t* LdsBytes;
+    typedef uint32_t Pair __attribute__((ext_vector_type(2)));   // a built-in vector type: loads through an LDS pointer
+    typedef __attribute__((address_space(3))) const Pair* LdsEntry;
+    const uint32_t table = (uint32_t)(uintptr_t)(LdsBytes) reinterpret_cast<const uint8_t*>(ac_tab);
+    // at_run + 8 f is the entry (run, 32 - f): entry 16 run + 16 - (32 - f)
+    const uint32_t run_0 = table - 16u * 8u;
+    const uint32_t zrl_from = run_0 + 16 * 128;   // from run 16 on
+    uint32_t at_run = run_0;
+    uint32_t fewest_sign_bits = 32;               // over the AC values: 32 - size category
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const uint32_t any = (g == 0 ? (blk.w[0] & 0xffff0000u) : blk.w[4 * g]) | blk.w[4 * g + 1] | blk.w[4 * g + 2] |
+                             blk.w[4 * g + 3];
+        if (any == 0) {
+            at_run += (g == 0) ? 7 * 128 : 8 * 128;
+            continue;
+        }
+#pragma unroll
+        for (int k = (g == 0 ? 1 : 8 * g); k < 8 * g + 8; ++k) {
+            const int v = blk.at(k);
+            if (v != 0) {
+                while (at_run >= zrl_from) {
+                    const Pair z = *(LdsEntry)(uintptr_t)(table + HuffTop::kZrl * 8u);
+                    sink.put_top(z.x & ~31u, z.y);
+                    at_run -= 16 * 128;
+                }
+                const int t = v + (v >> 31);
+                uint32_t f;   // leading bits of t that equal its sign (t is neither 0 nor -1)
+                asm("v_ffbh_i32 %0, %1" : "=v"(f) : "v"(t));
+                if (kChecked) {
+                    fewest_sign_bits = f < fewest_sign_bits ? f : fewest_sign_bits;
+                    f = f > 22u ? f : 22u;                           // keeps the entry and the bit count in range when the value is not
+                }
+                const Pair e = *(LdsEntry)(uintptr_t)(at_run + (f << 3));
+                const uint32_t low_bits_on_top = (uint32_t)t << f;   // the 32 - f low bits of t
+                sink.put_top((e.x & ~31u) | (low_bits_on_top >> e.x), e.y);
+                at_run = run_0;
+            } else {
+                at_run += 128;
+            }
+        }
+    }
+    if (fewest_sign_bits < 22u) ok = false;
+    if (at_run != run_0) {  // zz[63] == 0: trailing zeros (and their ZRLs) collapse into EOB
+        const Pair e = *(LdsEntry)(uintptr_t)(table + HuffTop::kEob * 8u);
+        sink.put_top(e.x & ~31u, e.y);
+    }
+    return ok;
+}
+
 // Places j of w0 (bit 31-j), within `valid`, from which on w0:w1 holds eight ones: where a 0xFF byte starts if
 // a byte boundary falls there.  Returned as eight 8-bit tallies by j mod 8 (at most four each).
 __device__ __forceinline__ uint64_t ff_places(uint32_t w0, uint32_t w1, uint32_t valid) {
