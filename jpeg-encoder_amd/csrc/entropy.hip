@@ -459,12 +459,23 @@ __global__ __launch_bounds__(kEntThreads) void stuff_kernel(uint32_t n_tiles, co
 __device__ __forceinline__ void or_strings(uint32_t* win, const uint32_t* __restrict__ slot, uint32_t my_len,
                                            uint32_t start, uint32_t wlo) {
     const uint32_t my_words = (my_len + 31) >> 5, sh = start & 31u, first = start >> 5;
-    for (uint32_t w = 0; w < my_words; ++w) {
-        const uint32_t idx = first + w - wlo;        // wraps below the window: rejected by the range tests
-        if (idx <= kWinWords || idx == 0xffffffffu) {
-            const uint32_t v = slot[(size_t)w * kSlotStride];
-            if (idx <= kWinWords) atomicOr(&win[idx], v >> sh);
-            if (sh != 0 && idx + 1 <= kWinWords) atomicOr(&win[idx + 1], v << (32u - sh));
+    // Eight loads under way at a time: as one loop, every word's load is waited for before the next is issued,
+    // and a string of noise (a dozen words) then costs a dozen trips to memory, one after the other.
+    constexpr uint32_t kBatch = 8;
+    for (uint32_t w0 = 0; w0 < my_words; w0 += kBatch) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t w = w0 + k, idx = first + w - wlo;   // wraps below the window: rejected by the range tests
+            v[k] = (w < my_words && (idx <= kWinWords || idx == 0xffffffffu)) ? slot[(size_t)w * kSlotStride] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t w = w0 + k, idx = first + w - wlo;
+            if (w < my_words && (idx <= kWinWords || idx == 0xffffffffu)) {
+                if (idx <= kWinWords) atomicOr(&win[idx], v[k] >> sh);
+                if (sh != 0 && idx + 1 <= kWinWords) atomicOr(&win[idx + 1], v[k] << (32u - sh));
+            }
         }
     }
 }
@@ -532,38 +543,45 @@ __global__ __launch_bounds__(kEntThreads, 8) void tile_bits_kernel(const int16_t
         const uint32_t len1 = lens[threadIdx.x + 1], len2 = lens[threadIdx.x + 2];
         const uint32_t head1 = len1 ? slot[1] : 0u, head2 = (len1 < 32 && len2) ? slot[2] : 0u;
         const uint32_t following = head1 | (len1 < 32 ? head2 >> len1 : 0u);
-        const uint32_t n_words = (my_len + 31) >> 5, rem = my_len & 31u;
-        // the partial last word is filled up with the following bits; after it come the rest of those
+        // The string's words as the stream has them: the partial last word filled up with the following bits, and the
+        // rest of those after it.  Every place of the words before the last counts, of the last those of its own bits.
+        const uint32_t rem = my_len & 31u, last = (my_len - 1) >> 5;   // a string has at least four bits
+        const uint32_t fill = rem ? following >> rem : 0u;
         const uint32_t after = rem ? following << (32u - rem) : following;
-        uint32_t cur = slot[0];
-        if (n_words == 1 && rem) cur |= following >> rem;
-        uint64_t t = 0;
-        for (uint32_t i0 = 0; i0 < n_words; i0 += 4) {   // four loads under way at a time
+        FfTally tally;
+        uint32_t cur = slot[0] | (last == 0 ? fill : 0u);
+        uint32_t batches = 0;
+        for (uint32_t i0 = 0; i0 < last; i0 += 4) {   // four loads under way at a time
             uint32_t w[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k)
-                w[k] = (i0 + k + 1 < n_words) ? slot[(size_t)(i0 + k + 1) * kSlotStride] : 0u;
+                w[k] = (i0 + k + 1 <= last) ? slot[(size_t)(i0 + k + 1) * kSlotStride] : 0u;
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
                 const uint32_t i = i0 + k;
-                if (i < n_words) {
-                    uint32_t next = after;
-                    if (i + 1 < n_words) {
-                        next = w[k];
-                        if (i + 2 == n_words && rem) next |= following >> rem;
-                    }
-                    t += ff_places(cur, next, (i + 1 == n_words && rem) ? ~0u << (32u - rem) : ~0u);
+                if (i < last) {
+                    const uint32_t next = w[k] | (i + 1 == last ? fill : 0u);
+                    const uint32_t m = ff_starts(cur, next);
+                    if (m != 0) tally.add(m);
                     cur = next;
                 }
             }
+            if (++batches == 3) {   // twelve words: the tally's fields hold fifteen
+                tally.flush();
+                batches = 0;
+            }
         }
-        if (t != 0) {
+        const uint32_t m_last = ff_starts(cur, after) & (rem ? ~0u << (32u - rem) : ~0u);
+        if (m_last != 0) tally.add(m_last);
+        tally.flush();
+        uint32_t any = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 8; ++r) any |= tally.total[r];
+        if (any != 0) {
             const uint32_t shift = local_off & 7u;
 #pragma unroll
-            for (uint32_t r = 0; r < 8; ++r) {
-                const uint32_t n = (uint32_t)(t >> (8u * r)) & 0xffu;
-                if (n) atomicAdd(&count[(r + shift) & 7u], n);
-            }
+            for (uint32_t r = 0; r < 8; ++r)
+                if (tally.total[r]) atomicAdd(&count[(r + shift) & 7u], tally.total[r]);
         }
     }
     __syncthreads();

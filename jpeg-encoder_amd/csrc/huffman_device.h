@@ -325,20 +325,37 @@ __device__ __forceinline__ bool encode_block_top(const BlockRegs& blk, int prev_
     return ok;
 }
 
-// Places j of w0 (bit 31-j), within `valid`, from which on w0:w1 holds eight ones: where a 0xFF byte starts if
-// a byte boundary falls there.  Returned as eight 8-bit tallies by j mod 8 (at most four each).
-__device__ __forceinline__ uint64_t ff_places(uint32_t w0, uint32_t w1, uint32_t valid) {
+// Places j of w0 (bit 31-j) from which on w0:w1 holds eight ones: where a 0xFF byte starts if a byte boundary falls
+// there.  Bit 31-j of the result.
+__device__ __forceinline__ uint32_t ff_starts(uint32_t w0, uint32_t w1) {
     // runs of 2, 4, 8 ones by doubling; of the low word only the top bits matter, which its own shifts get right
     const uint32_t a0 = w0 & __builtin_amdgcn_alignbit(w0, w1, 31), a1 = w1 & (w1 << 1);
     const uint32_t b0 = a0 & __builtin_amdgcn_alignbit(a0, a1, 30), b1 = a1 & (a1 << 2);
-    const uint32_t m = b0 & __builtin_amdgcn_alignbit(b0, b1, 28) & valid;
-    uint64_t t = 0;
-    if (m != 0) {
-#pragma unroll
-        for (uint32_t r = 0; r < 8; ++r) t |= (uint64_t)__popc(m & (0x80808080u >> r)) << (8u * r);
-    }
-    return t;
+    return b0 & __builtin_amdgcn_alignbit(b0, b1, 28);
 }
+
+// Tallies of such places by j mod 8, over the words of one string.  A word's places are counted in 4-bit fields,
+// all eight residues of all four bytes with four masks and four sums (a population count per residue is sixteen
+// instructions and eight registers); a field holds up to fifteen words' worth and is then flushed into the
+// per-residue totals, the four fields of a residue summed by one sum-of-bytes instruction.
+struct FfTally {
+    uint32_t field[4] = {0, 0, 0, 0};   // field[k], nibble n: places at bit 4 n + k
+    uint32_t total[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // by j mod 8
+    __device__ __forceinline__ void add(uint32_t m) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) field[k] += (m >> k) & 0x11111111u;
+    }
+    // after at most fifteen add()
+    __device__ __forceinline__ void flush() {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            // bit p is place j = 31 - p: even nibbles (p mod 8 = k) are residue 7 - k, odd ones residue 3 - k
+            total[7 - k] = __builtin_amdgcn_sad_u8(field[k] & 0x0f0f0f0fu, 0u, total[7 - k]);
+            total[3 - k] = __builtin_amdgcn_sad_u8((field[k] >> 4) & 0x0f0f0f0fu, 0u, total[3 - k]);
+            field[k] = 0;
+        }
+    }
+};
 
 // Bit reader over a stream from which the stuffed zeros have already been removed (the per-block entry points:
 // their callers unstuff first, as encoder.cpp:49 does).
