@@ -178,14 +178,58 @@ class Job:
         ordered = sorted(regions)
         return ordered[len(ordered) // 2], regions
 
-    def finish(self, out):
+    def close(self):
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+            self.dist = None
+
+    def emit(self, out):
         out["ranks_seen"] = self.ranks_seen
         out["comm_backend"] = self.comm_name
         if self.rank == 0:
             print(json.dumps(out), flush=True)
+
+    def finish(self, out):
+        self.close()
+        self.emit(out)
+
+    def finish_after(self, out, name, measure, seconds):
+        """Runs measure() -- a measurement with collectives in it that this build could not run on several GPUs -- and
+        the closing barrier on a thread with a time limit, so that the headline line is printed whatever becomes of it:
+        out["other_measurements"][name] is its line, or says what failed.  A rank whose thread is still stuck when the
+        limit passes prints (rank 0) and leaves without the barrier; every rank has the same limit."""
+        import threading
+
+        box = {}
+
+        def work():
+            try:
+                self.torch.cuda.set_device(self.device_index)
+                box["line"] = embedded(measure())
+            except Exception as e:   # noqa: BLE001  (an operation the installed RCCL / torch refuses, on every rank alike)
+                box["line"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                self.close()
+                box["closed"] = True
+            except Exception as e:   # noqa: BLE001
+                box["close_error"] = "%s: %s" % (type(e).__name__, e)
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(seconds)
+        extra = out.setdefault("other_measurements", {})
+        if "line" in box:
+            extra[name] = box["line"]
+        else:
+            extra[name] = {"error": "did not finish within %d s" % seconds}
+        if t.is_alive() or "closed" not in box:
+            if "line" in box and "error" not in box["line"]:
+                extra[name]["note"] = "the closing barrier did not finish within the limit"
+            self.emit(out)
+            sys.stdout.flush()
+            os._exit(0)
+        self.emit(out)
 
 
 def region_stats(regions):
@@ -843,12 +887,10 @@ def main():
             extra["c3_batch_of_1024_1080p_q90"] = embedded(config_c3(job, *defaults_of["c3"], with_cpu=False))
             extra["c5_decode_of_1024_1080p_q50"] = embedded(config_c5(job, *defaults_of["c5"], with_cpu=False))
         else:
-            # (an exception that every rank meets alike -- an operation the installed RCCL / torch refuses -- must not cost
-            # the headline line; the entry then says what failed)
-            try:
-                extra["c4_16384x16384_as_stripes"] = embedded(config_c4(job, *defaults_of["c4"], with_cpu=False))
-            except Exception as e:   # noqa: BLE001
-                extra["c4_16384x16384_as_stripes"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            limit = int(os.environ.get("JEA_C4_LIMIT_SECONDS", "240"))
+            job.finish_after(out, "c4_16384x16384_as_stripes",
+                             lambda: config_c4(job, *defaults_of["c4"], with_cpu=False), limit)
+            return
     job.finish(out)
 
 

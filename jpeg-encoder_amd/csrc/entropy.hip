@@ -74,6 +74,32 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + incl - v;
 }
 
+// A barrier for threads that have exchanged data through LDS only.  __syncthreads() also orders global memory:
+// it waits for every store the wave has under way, and a loop that stores to memory and then meets a barrier
+// pays the stores' latency once per turn.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The same scan with one barrier of the LDS-only kind; `lds4`: four words that the call before this one did not use
+// (two sets, taken in turn).
+__device__ __forceinline__ uint32_t block_exclusive_scan_256_lds(uint32_t v, uint32_t* lds4, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) lds4[wave] = incl;
+    lds_barrier();
+    uint32_t base = 0;
+    const uint32_t s0 = lds4[0], s1 = lds4[1], s2 = lds4[2], s3 = lds4[3];
+    if (wave > 0) base += s0;
+    if (wave > 1) base += s1;
+    if (wave > 2) base += s2;
+    total = s0 + s1 + s2 + s3;
+    return base + incl - v;
+}
+
 template <bool kEmit>
 __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* __restrict__ coefs, uint32_t nbc,
                                                                  uint32_t n_tiles,
@@ -672,8 +698,9 @@ __global__ __launch_bounds__(1024) void scan_tiles_ff_kernel(const uint32_t* __r
 // thread a 4K picture of noise encoded at 134 instead of 141 GPix/s).
 template <uint32_t kWords>
 __device__ __forceinline__ void stuff_window(const uint32_t* win, uint32_t words_here, uint64_t win_byte, uint64_t b0,
-                                             uint64_t b1, uint8_t* dst, uint64_t& carry, uint32_t* wsum) {
-    for (uint32_t w0 = 0; w0 < words_here; w0 += kEntThreads * kWords) {
+                                             uint64_t b1, uint8_t* dst, uint64_t& carry, uint32_t* wsum8) {
+    uint32_t turn = 0;
+    for (uint32_t w0 = 0; w0 < words_here; w0 += kEntThreads * kWords, turn ^= 4u) {
         const uint32_t wi = w0 + threadIdx.x * kWords;
         uint32_t bytes[4 * kWords];
         uint32_t owned = 0, cnt = 0;
@@ -689,7 +716,7 @@ __device__ __forceinline__ void stuff_window(const uint32_t* win, uint32_t words
             }
         }
         uint32_t total;
-        uint32_t pos = block_exclusive_scan_256(cnt, wsum, total);
+        uint32_t pos = block_exclusive_scan_256_lds(cnt, wsum8 + turn, total);   // the stores of the turn before stay under way
         uint8_t* const to = dst + (win_byte + (uint64_t)wi * 4 + carry);
 #pragma unroll
         for (uint32_t k = 0; k < 4 * kWords; ++k) {
@@ -701,7 +728,7 @@ __device__ __forceinline__ void stuff_window(const uint32_t* win, uint32_t words
                 }
             }
         }
-        carry += total;   // the scan's last barrier is also what lets the next window be cleared
+        carry += total;
     }
 }
 
@@ -722,7 +749,7 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
                                                                     uint8_t* __restrict__ out, uint64_t out_capacity,
                                                                     int32_t* __restrict__ status) {
     __shared__ uint32_t win[kWinWords + 2];
-    __shared__ uint32_t wsum[4], psum[8], fsum[4];
+    __shared__ uint32_t wsum[8], psum[8], fsum[4];
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const int32_t status_now = *status;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;

@@ -51,3 +51,21 @@ def test_bench_c4_over_rccl_with_one_rank():
                   JEA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["comm_backend"] == "nccl (RCCL)"
     assert line["config"]["file_checked_against"] == "oracle, byte for byte"
+
+
+def test_default_run_on_two_ranks_carries_the_stripe_measurement():
+    line = _bench("--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--c4-size", "2048", "--pool", "2",
+                  JEA_DIST_BACKEND="gloo")
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["value"] > 0
+    c4 = line["other_measurements"]["c4_16384x16384_as_stripes"]
+    assert "error" not in c4, c4
+    assert c4["config"]["file_checked_against"] == "oracle, byte for byte" and c4["value"] > 0
+
+
+def test_default_run_prints_its_line_when_the_stripe_measurement_does_not_finish():
+    """The measurement with collectives runs under a time limit: with a limit of zero the headline line must still
+    appear, say what happened, and the ranks must leave with exit code 0."""
+    line = _bench("--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--c4-size", "2048", "--pool", "2",
+                  JEA_DIST_BACKEND="gloo", JEA_C4_LIMIT_SECONDS="0")
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "did not finish" in line["other_measurements"]["c4_16384x16384_as_stripes"]["error"]
