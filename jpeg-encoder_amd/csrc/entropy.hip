@@ -41,6 +41,8 @@
 #include <hip/hip_runtime.h>
 
 #include "huffman_device.h"
+#include <type_traits>
+
 #include "kernels.h"
 #include "tables.h"
 #include "../../include/jpegenc_amd.h"
@@ -72,6 +74,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     total = s0 + s1 + s2 + s3;
     __syncthreads();
     return base + incl - v;
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {   // a value that is the same in every lane of the wave
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
 }
 
 // A barrier for threads that have exchanged data through LDS only.  __syncthreads() also orders global memory:
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
                                                                  const uint8_t* __restrict__ chunk_masks,
                                                                  ComponentMode mode,
                                                                  const int16_t* __restrict__ d_initial_dc = nullptr) {
-    __shared__ HuffLds h;
+    __shared__ std::conditional_t<kEmit, HuffTop, HuffLds> h;   // the writer's tables, or the plain codes for counting
     __shared__ uint32_t wsum[4];
     const uint32_t tile = blockIdx.x, img = blockIdx.y;
     const uint32_t b = tile * kTileBlocks + threadIdx.x;
@@ -128,18 +135,18 @@ __global__ __launch_bounds__(kEntThreads) void block_bits_kernel(const int16_t* 
         // (d_initial_dc: the same three values in device memory, where another stripe's owner has put them)
         prev_dc = (b >= 3) ? (int)p[-192] : (d_initial_dc != nullptr ? (int)d_initial_dc[b] : (int)st.initial_dc[b]);
     }
-    load_huff<kEntThreads>(h, huff);
+    if constexpr (kEmit) load_huff_top<kEntThreads>(h, huff);
+    else load_huff<kEntThreads>(h, huff);
     __syncthreads();
     uint32_t bits = 0;
     if (has_block) {
         bool ok;
         const int cls = mode.is_lum((uint32_t)ch) ? 0 : 1;   // Huffman table class (encoder.cpp:25)
-        if (kEmit) {
-            SlotSink sink;
-            sink.slot = slots + ((size_t)img * n_tiles + tile) * kSlotWords * kSlotStride + threadIdx.x;
-            ok = encode_block(blk, prev_dc, h.dc[cls], h.ac[cls], sink);
+        if constexpr (kEmit) {
+            TopSink sink(slots + ((size_t)img * n_tiles + tile) * kSlotWords * kSlotStride, threadIdx.x);
+            ok = encode_block_top<true>(blk, prev_dc, h.dc[cls], h.ac[cls], sink);
             sink.finish();
-            bits = sink.bits;
+            bits = sink.bits();
         } else {
             CountSink sink;
             ok = encode_block(blk, prev_dc, h.dc[cls], h.ac[cls], sink);
@@ -696,39 +703,46 @@ __global__ __launch_bounds__(1024) void scan_tiles_ff_kernel(const uint32_t* __r
 // step's instructions are not spent on threads without bytes; long ones two: the fewer bytes a thread has,
 // the closer together lie the bytes that one store instruction of the wave writes (with four words per
 // thread a 4K picture of noise encoded at 134 instead of 141 GPix/s).
+// The window's bytes [own_from, own_to) are the owned ones (own_to at most 4 * words_here); `out0`: where the window's
+// byte 0 goes if no 0xFF of this tile precedes it -- the same for the whole workgroup and handed to the stores as
+// such (a scalar base and a 32-bit offset per lane: one sum per store instead of two 64-bit ones); carry: the
+// tile's 0xFF bytes so far.
 template <uint32_t kWords>
-__device__ __forceinline__ void stuff_window(const uint32_t* win, uint32_t words_here, uint64_t win_byte, uint64_t b0,
-                                             uint64_t b1, uint8_t* dst, uint64_t& carry, uint32_t* wsum8) {
+__device__ __forceinline__ void stuff_window(const uint32_t* win, uint32_t words_here, uint32_t own_from, uint32_t own_to,
+                                             uint8_t* out0, uint32_t& carry, uint32_t* wsum8) {
     uint32_t turn = 0;
     for (uint32_t w0 = 0; w0 < words_here; w0 += kEntThreads * kWords, turn ^= 4u) {
         const uint32_t wi = w0 + threadIdx.x * kWords;
         uint32_t bytes[4 * kWords];
         uint32_t owned = 0, cnt = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 4 * kWords; ++k) {
-            const uint32_t word = wi + (k >> 2);
-            const uint64_t x = win_byte + (uint64_t)word * 4 + (k & 3);      // stream byte index
+        for (uint32_t j = 0; j < kWords; ++j) {
+            const uint32_t word = wi + j;
             const uint32_t v = word < words_here ? win[word] : 0u;
-            bytes[k] = (v >> (24 - 8 * (k & 3))) & 0xffu;
-            if (word < words_here && x >= b0 && x < b1) {
-                owned |= 1u << k;
-                cnt += bytes[k] == 0xffu;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t k = 4 * j + q, x = 4 * word + q;   // window byte index
+                bytes[k] = (v >> (24 - 8 * q)) & 0xffu;
+                if (x >= own_from && x < own_to) {
+                    owned |= 1u << k;
+                    cnt += bytes[k] == 0xffu;
+                }
             }
         }
         uint32_t total;
         uint32_t pos = block_exclusive_scan_256_lds(cnt, wsum8 + turn, total);   // the stores of the turn before stay under way
-        uint8_t* const to = dst + (win_byte + (uint64_t)wi * 4 + carry);
+        pos += 4 * wi + carry;
 #pragma unroll
         for (uint32_t k = 0; k < 4 * kWords; ++k) {
             if ((owned >> k) & 1u) {
-                to[k + pos] = (uint8_t)bytes[k];
+                out0[k + pos] = (uint8_t)bytes[k];
                 if (bytes[k] == 0xffu) {
                     ++pos;
-                    to[k + pos] = 0x00;
+                    out0[k + pos] = 0x00;
                 }
             }
         }
-        carry += total;
+        carry += (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
     }
 }
 
@@ -849,6 +863,10 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
         if ((psum[0] | psum[1] | psum[2] | psum[3]) != 0u) return;
         own_ff = ff_at(own_ff8, (uint32_t)base_bits);
     }
+    // The same in every lane, but out of sums that each lane made for itself: as scalars again, so that what follows
+    // from them -- the window's place in the file above all -- is worked out once, not per lane.
+    base_bits = uniform64(base_bits);
+    ff_before = uniform64(ff_before);
     const uint64_t end_bits = base_bits + own_bits;
     const uint64_t b0 = (base_bits + 7) >> 3, b1 = (end_bits + 7) >> 3;  // owned bytes [b0, b1) of the unstuffed stream
     uint8_t* file = out;
@@ -888,17 +906,22 @@ __global__ __launch_bounds__(kEntThreads, 7) void pack_stuff_kernel(uint32_t nbc
     const uint32_t slot_col = threadIdx.x < kTileBlocks ? threadIdx.x : threadIdx.x - kTileBlocks;
     const uint32_t* slot = slots + ((size_t)img * n_tiles + slot_tile) * kSlotWords * kSlotStride + slot_col;
     uint8_t* const dst = file + header_len + ff_before;      // + stream byte index + 0xFFs of this tile before it
-    uint64_t carry = 0;
+    uint32_t carry = 0;   // at most 252 * 1660 / 8 bytes a tile
     for (uint32_t wlo = 0; wlo < n_words; wlo += kWinWords) {
         const uint32_t words_here = (n_words - wlo < kWinWords) ? (n_words - wlo) : kWinWords;
         for (uint32_t i = threadIdx.x; i < words_here + 1; i += kEntThreads) win[i] = 0;
         __syncthreads();
         or_strings(win, slot, my_len, rel_start, wlo);
         __syncthreads();
+        // owned bytes relative to the window: b0 lies in its first word or before the later windows, b1 at or after its start
+        const uint64_t win_byte = (d0 + wlo) * 4;
+        const uint32_t own_from = b0 > win_byte ? (uint32_t)(b0 - win_byte) : 0u;
+        const uint64_t left = b1 > win_byte ? b1 - win_byte : 0;
+        const uint32_t own_to = left < 4ull * words_here ? (uint32_t)left : 4u * words_here;
         if (words_here <= kEntThreads)
-            stuff_window<1>(win, words_here, (d0 + wlo) * 4, b0, b1, dst, carry, wsum);
+            stuff_window<1>(win, words_here, own_from, own_to, dst + win_byte, carry, wsum);
         else
-            stuff_window<2>(win, words_here, (d0 + wlo) * 4, b0, b1, dst, carry, wsum);
+            stuff_window<2>(win, words_here, own_from, own_to, dst + win_byte, carry, wsum);
     }
 }
 
