@@ -311,16 +311,17 @@ __global__ __launch_bounds__(kThreads) void unstuff_compact_kernel(const uint8_t
 // Sub-sequence decoding
 // ---------------------------------------------------------------------------
 
-// The words of one workgroup's 256 sub-sequences plus a tail, as MSB-first values.  Layout: a dummy
-// word, then the stream words; after every W words one padding word, so that threads reading the
-// same word of their own sub-sequences hit different LDS banks.
+// The words of one workgroup's 256 sub-sequences plus a tail, as MSB-first values: a dummy word, then the stream
+// words.  No padding between the sub-sequences: the threads start on the same word of their own sub-sequences (which
+// lie W words apart: a 16-way bank conflict, once) but are at unrelated words after a symbol or two, padded or not,
+// and the two instructions a padded index costs at every step of a walk were 1-2 % of the passes' time.
 // kTail: words staged past the group; the window below looks three words past the one that holds the
 // last bit of a sub-sequence.
 template <uint32_t W, uint32_t kTail = 3>
 struct GroupWords {
     static constexpr uint32_t kWords = kThreads * W + kTail;   // staged stream words
-    uint32_t w[(kWords + 1) + (kWords + 1) / W + 1];
-    static __device__ __forceinline__ uint32_t slot(uint32_t index) { return index + index / W; }   // index 0 = the dummy
+    uint32_t w[kWords + 2];
+    static __device__ __forceinline__ uint32_t slot(uint32_t index) { return index; }   // index 0 = the dummy
 };
 
 // first_sub: sub-sequence held by the first slot; negative slots (before the stream) read as zero.
