@@ -23,7 +23,9 @@ c3-c5, whose total work is fixed).
 
 The default run (c2) also carries, under `other_measurements`, the other configurations at their full sizes: with one
 rank c3 and c5 (1024 frames each), with several ranks c4 (the stripe protocol with its collectives, file hash
-checked) -- each with the steps and warm-up of its own defaults; none of them is `value`.
+checked) -- each with the steps and warm-up of its own defaults; none of them is `value`.  The c4 measurement of a
+multi-rank run and the closing barrier run under a time limit (JEA_C4_LIMIT_SECONDS, default 240): whatever becomes of
+its collectives, rank 0 prints the headline line, with the measurement or with what happened to it.
 
 Timing: after an untimed ramp and W warm-up steps, regions of exactly K steps each are timed, every one
 bracketed by a barrier and a device synchronisation on both sides; as many regions as fit 50 ms (one, when K
