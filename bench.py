@@ -171,9 +171,10 @@ class Job:
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
-            sync()
-            self.torch.cuda.synchronize(self.dev)
-            regions.append(self.max_over_ranks(time.perf_counter() - t0))   # the job's time: the slowest rank's
+            self.torch.cuda.synchronize(self.dev)   # the device, i.e. every context's stream
+            seconds = time.perf_counter() - t0
+            sync()                                  # nothing left to wait for: the contexts report their errors
+            regions.append(self.max_over_ranks(seconds))   # the job's time: the slowest rank's
             if len(regions) == 1:
                 want = int(min(60, max(1, math.ceil(MIN_TIMED_SECONDS / max(regions[0], 1e-9)))))
         self.barrier(sync)
