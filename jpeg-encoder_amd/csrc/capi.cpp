@@ -1710,6 +1710,59 @@ bool is_pinned(const void* p) {
     return a.type == hipMemoryTypeHost;
 }
 
+// Pixels on their way back to host memory that the GPU can write (pinned): a kernel of a few workgroups instead of
+// hipMemcpyAsync.  The runtime's copy from device memory to pinned host memory is a kernel too, one that fills the
+// GPU: the decoder's kernels of the next piece, which should run beside it, got their workgroups in only as its
+// workgroups left (a 4K picture's first decode kernel then took 180 us instead of 34), the next copy started late,
+// and the link idled a fifth of the time.  JEA_TO_HOST_GROUPS workgroups keep the link as busy and leave the rest of
+// the GPU alone.
+#ifndef JEA_TO_HOST_GROUPS
+#define JEA_TO_HOST_GROUPS 32
+#endif
+typedef uint32_t Words4 __attribute__((ext_vector_type(4)));   // a built-in vector type, as the non-temporal loads want
+__global__ __launch_bounds__(256) void to_host_kernel(const Words4* __restrict__ src, Words4* __restrict__ dst, size_t n16,
+                                                      size_t tail_bytes) {
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // four loads, then four stores: enough bytes under way per lane to cover the link's latency
+    for (; i + 3 * step < n16; i += 4 * step) {
+        const Words4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + step),
+                     c = __builtin_nontemporal_load(src + i + 2 * step), d = __builtin_nontemporal_load(src + i + 3 * step);
+        dst[i] = a;
+        dst[i + step] = b;
+        dst[i + 2 * step] = c;
+        dst[i + 3 * step] = d;
+    }
+    for (; i < n16; i += step) dst[i] = __builtin_nontemporal_load(src + i);
+    if (blockIdx.x == 0 && threadIdx.x < tail_bytes)
+        reinterpret_cast<uint8_t*>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint8_t*>(src + n16)[threadIdx.x];
+}
+
+// Device memory to pinned host memory on `stream`: the kernel above where the addresses allow 16-byte pieces.
+// `chunk`: bytes per launch.  A kernel of another stream that runs beside such a copy does not end before the copy's
+// launch has ended (the first decode kernel of the next piece, 34 us alone, ended 20 us after a whole-piece copy of
+// 455 us, whatever it wrote), so a caller with time to spare for the launches cuts the copy into short ones:
+// 64 x 4K pictures into the caller's pinned memory, one launch per piece 46.3 GB/s, 2 MB per launch 48.5, 1 MB 49.3;
+// into staging memory that the host then copies on (pageable caller memory: the host is the busy one) 43.5 / 42.2 / 40.9.
+int copy_to_pinned(jea_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, hipStream_t stream, size_t chunk) {
+    void* mapped = nullptr;
+    if (bytes >= (1u << 20) && (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0 &&
+        hipHostGetDevicePointer(&mapped, h_dst, 0) == hipSuccess && mapped != nullptr &&
+        (reinterpret_cast<uintptr_t>(mapped) & 15u) == 0) {
+        chunk = (chunk + 15) / 16 * 16;
+        for (size_t at = 0; at < bytes; at += chunk) {
+            const size_t len = bytes - at < chunk ? bytes - at : chunk;
+            to_host_kernel<<<JEA_TO_HOST_GROUPS, 256, 0, stream>>>((const Words4*)((const uint8_t*)d_src + at),
+                                                                   (Words4*)((uint8_t*)mapped + at), len / 16, len % 16);
+        }
+        JEA_HIP(ctx, hipGetLastError());
+        return JEA_OK;
+    }
+    (void)hipGetLastError();
+    JEA_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
+    return JEA_OK;
+}
+
 size_t images_per_piece(size_t image_bytes, size_t n_images) {
     size_t k = ((size_t)32 << 20) / image_bytes;
     if (k < 1) k = 1;
@@ -1866,11 +1919,21 @@ int jea_decode_host_batch(jea_ctx* ctx, const uint8_t* h_jpeg, const uint64_t* h
     int result = JEA_OK;
     // per round: the pixels of piece p-2 reach the caller's memory, then piece p's files go in and are decoded (the
     // decode waits for the GPU itself), then its pixels start back -- while the pixels of piece p-1 are still on the link
+    // (pageable caller memory: that last copy, a third of a millisecond of host time for a piece, runs on a thread of
+    // its own beside the decode call of the round and is waited for before the slot's staging memory is written again)
+    std::thread to_caller;
+    auto join_to_caller = [&to_caller] { if (to_caller.joinable()) to_caller.join(); };
     for (size_t p = 0; p < n_pieces + 2 && result == JEA_OK; ++p) {
         if (p >= 2) {
             PipeSlot& sl = ctx->pipe[p & 1];
-            JEA_HIP(ctx, hipEventSynchronize(sl.d2h));
-            if (!out_pinned) parallel_memcpy(h_rgb + (p - 2) * k * image_bytes, sl.pin_out, images_of(p - 2) * image_bytes);
+            const hipError_t e = hipEventSynchronize(sl.d2h);
+            if (e != hipSuccess) { result = fail(ctx, JEA_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e)); break; }
+            if (!out_pinned) {
+                uint8_t* const to = h_rgb + (p - 2) * k * image_bytes;
+                const void* const from = sl.pin_out;
+                const size_t bytes = images_of(p - 2) * image_bytes;
+                to_caller = std::thread([=] { parallel_memcpy(to, from, bytes); });
+            }
         }
         if (p < n_pieces) {
             PipeSlot& sl = ctx->pipe[p & 1];
@@ -1882,15 +1945,23 @@ int jea_decode_host_batch(jea_ctx* ctx, const uint8_t* h_jpeg, const uint64_t* h
                 std::memcpy((uint8_t*)sl.pin_in + at, h_jpeg + h_offsets[p * k + i], (size_t)sizes[i]);
                 at += ((size_t)sizes[i] + 63) / 64 * 64;
             }
-            JEA_HIP(ctx, hipMemcpyAsync(sl.d_in.ptr, sl.pin_in, at, hipMemcpyHostToDevice, ctx->stream));
+            {   // (no early return in this loop: the thread above may be running)
+                const hipError_t e = hipMemcpyAsync(sl.d_in.ptr, sl.pin_in, at, hipMemcpyHostToDevice, ctx->stream);
+                if (e != hipSuccess) { result = fail(ctx, JEA_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
+            }
             rc = jea_decode_batch(ctx, (const uint8_t*)sl.d_in.ptr, offs.data(), sizes.data(), n, width, height, lum_q, chr_q,
                                   (uint8_t*)sl.d_out.ptr);
             if (rc) { result = rc; break; }
+            join_to_caller();   // piece p-2 has left this slot's staging memory
             uint8_t* dst = out_pinned ? h_rgb + p * k * image_bytes : (uint8_t*)sl.pin_out;
-            JEA_HIP(ctx, hipMemcpyAsync(dst, sl.d_out.ptr, n * image_bytes, hipMemcpyDeviceToHost, ctx->copy_out));
-            JEA_HIP(ctx, hipEventRecord(sl.d2h, ctx->copy_out));
+            if ((rc = copy_to_pinned(ctx, dst, sl.d_out.ptr, n * image_bytes, ctx->copy_out,
+                                     out_pinned ? (size_t)1 << 20 : n * image_bytes))) { result = rc; break; }
+            const hipError_t e = hipEventRecord(sl.d2h, ctx->copy_out);
+            if (e != hipSuccess) { result = fail(ctx, JEA_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); break; }
         }
+        if (p >= n_pieces) join_to_caller();
     }
+    join_to_caller();
     const int drained = drain_pipe(ctx);
     return result != JEA_OK ? result : drained;
 }

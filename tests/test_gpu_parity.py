@@ -952,7 +952,10 @@ def test_two_stream_batches_on_three_contexts_at_once(jea, po):
 
 
 @pytest.mark.parametrize("w,h,n,quality,pinned", [(200, 136, 7, 75, False), (1920, 1080, 13, 90, False), (3840, 2160, 5, 75, True),
-                                                  (640, 480, 130, 50, True)])
+                                                  (640, 480, 130, 50, True),
+                                                  # pictures whose size is no multiple of 16 bytes: the pixels' way back ends
+                                                  # in a few single bytes, and the second piece starts at an odd address
+                                                  (1001, 999, 13, 75, True), (1001, 999, 13, 75, False)])
 def test_host_batches_through_the_staging_pipeline(ctx, po, jea, w, h, n, quality, pinned):
     """Batches held in host memory: pieces of about 32 MB travel in, are coded and travel back on two staging slots.
     Files, offsets and sizes are those of the device-resident batch call; the decoded bitmaps are the oracle's.
