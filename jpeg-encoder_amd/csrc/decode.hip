@@ -384,19 +384,31 @@ __device__ __forceinline__ RawGroup stage_group_raw(GroupWords<W, kTail>& gw, co
     const uint64_t scan_end = len >= 2 ? len - 2 : 0;
     uint32_t carry = 0, kept_warm = 0, kept_to_group_end = 0;
     int32_t shift = 0;   // stream-byte index in the examined range -> byte index in the window
-    __syncthreads();     // the zeros are in place
+    lds_barrier();       // the zeros are in place
+    // A round's piece (and the byte before it) is asked for one round ahead; the barriers of a round order LDS only,
+    // so that load stays under way across them.
+    uint4 ahead = make_uint4(0, 0, 0, 0);
+    uint32_t ahead_before = 0;
+    auto ask = [&](uint32_t piece) {
+        const uint64_t j0 = raw0 + 16ull * piece;
+        if (piece < pieces && j0 + 16 <= len) {
+            __builtin_memcpy(&ahead, scan + j0, 16);
+            ahead_before = j0 > 0 ? scan[j0 - 1] : 0u;
+        }
+    };
+    ask(tid);
     for (uint32_t p0 = 0; p0 < pieces; p0 += kThreads) {
         const uint32_t piece = p0 + tid;
         const uint64_t j0 = raw0 + 16ull * piece;
-        uint8_t bytes[16];
+        uint8_t bytes[16] = {};
         uint32_t mask = 0, valid = 0;
         // Nearly every piece lies inside the scan and holds no 0xFF byte: nothing to drop, and its sixteen
         // bytes go out as whole words.  (The test may take a piece without 0xFF for one with: that is only slower.)
-        uint4 raw16 = make_uint4(0, 0, 0, 0);
+        const uint4 raw16 = ahead;
+        const bool after_ff = ahead_before == 0xFFu;
+        if (p0 + kThreads < pieces) ask(piece + kThreads);
         bool plain = false;
         if (piece < pieces && j0 + 16 <= len) {
-            __builtin_memcpy(&raw16, scan + j0, 16);
-            const bool after_ff = j0 > 0 && scan[j0 - 1] == 0xFFu;
             const uint32_t n0 = ~raw16.x, n1 = ~raw16.y, n2 = ~raw16.z, n3 = ~raw16.w;   // a zero byte here was 0xFF
             const uint32_t any_ff = (((n0 - 0x01010101u) & raw16.x) | ((n1 - 0x01010101u) & raw16.y) |
                                      ((n2 - 0x01010101u) & raw16.z) | ((n3 - 0x01010101u) & raw16.w)) & 0x80808080u;
@@ -415,7 +427,7 @@ __device__ __forceinline__ RawGroup stage_group_raw(GroupWords<W, kTail>& gw, co
             if (lane >= d) incl += t;
         }
         if (lane == 63) scratch[wave] = incl;
-        __syncthreads();
+        lds_barrier();
         uint32_t before = carry + incl - kept;
         for (int w = 0; w < wave; ++w) before += scratch[w];
         const uint32_t round_total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
@@ -423,7 +435,7 @@ __device__ __forceinline__ RawGroup stage_group_raw(GroupWords<W, kTail>& gw, co
         // fall between pieces, and the warm-up pieces all lie in the first round
         if (piece == warm_pieces) scratch[4] = before;
         if (piece == warm_pieces + group_pieces) scratch[5] = before;
-        __syncthreads();
+        lds_barrier();
         if (p0 == 0) {
             kept_warm = scratch[4];
             shift = (int32_t)warm_bytes - (int32_t)kept_warm;
@@ -445,15 +457,17 @@ __device__ __forceinline__ RawGroup stage_group_raw(GroupWords<W, kTail>& gw, co
 #pragma unroll
                 for (int k = 0; k < 16; ++k) bytes[k] = (uint8_t)((k < 4 ? raw16.x : (k < 8 ? raw16.y : (k < 12 ? raw16.z : raw16.w))) >> (8 * (k & 3)));
             }
-            for (uint32_t k = 0; k < valid; ++k) {
-                if ((mask >> k) & 1u) continue;
+            // (unrolled: with k a variable, bytes[] is an array in scratch memory)
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) {
+                if (k >= valid || ((mask >> k) & 1u)) continue;
                 if (q >= 0 && (uint32_t)q < G::kWords * 4u)
                     atomicOr(&gw.w[G::slot(((uint32_t)q >> 2) + 1)], (uint32_t)bytes[k] << (8u * (3u - ((uint32_t)q & 3u))));
                 ++q;
             }
         }
         carry += round_total;
-        __syncthreads();
+        lds_barrier();
     }
     RawGroup rg;
     const uint64_t examined_end = raw0 + 16ull * pieces;
@@ -495,12 +509,18 @@ __device__ __forceinline__ void load_tables(StepTables& t, const StepTables* __r
     constexpr uint32_t kPieces = sizeof(StepTables) / 16, kPerThread = (kPieces + kThreads - 1) / kThreads;
     const uint4* src = reinterpret_cast<const uint4*>(g);
     uint4* dst = reinterpret_cast<uint4*>(&t);
+    // (every element is loaded, from piece 0 where the thread has none: an array that is only partly assigned stays
+    // in scratch memory, and the copy then goes load, wait, scratch store four times over and back through scratch loads)
     uint4 v[kPerThread];
 #pragma unroll
     for (uint32_t r = 0; r < kPerThread; ++r) {
         const uint32_t i = r * kThreads + threadIdx.x;
-        if (i < kPieces) v[r] = src[i];
+        v[r] = src[i < kPieces ? i : 0u];
     }
+    // (the values are made opaque here, all loads issued: left alone the compiler sinks every load into the branch of
+    // its store -- load, wait, store, four trips to memory one after the other)
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; ++r) asm volatile("" : "+v"(v[r].x), "+v"(v[r].y), "+v"(v[r].z), "+v"(v[r].w));
 #pragma unroll
     for (uint32_t r = 0; r < kPerThread; ++r) {
         const uint32_t i = r * kThreads + threadIdx.x;
@@ -724,9 +744,13 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     const uint32_t c1 = next_channel(c0), c2 = next_channel(c1);
     // table class and running DC of the current channel and the two after it (see walk)
     uint32_t o0 = class_offset(lum_mask, c0), o1 = class_offset(lum_mask, c1), o2 = class_offset(lum_mask, c2);
-    int l0 = c0 == 0 ? wt.last0 : (c0 == 1 ? wt.last1 : wt.last2);
-    int l1 = c1 == 0 ? wt.last0 : (c1 == 1 ? wt.last1 : wt.last2);
-    int l2 = c2 == 0 ? wt.last0 : (c2 == 1 ? wt.last1 : wt.last2);
+    // (as opaque register values: left to itself the compiler turns these selections among three neighbouring fields
+    // into indexed loads, and the three fields into an array in scratch memory)
+    int by_channel0 = wt.last0, by_channel1 = wt.last1, by_channel2 = wt.last2;
+    asm volatile("" : "+v"(by_channel0), "+v"(by_channel1), "+v"(by_channel2));
+    int l0 = c0 == 0 ? by_channel0 : (c0 == 1 ? by_channel1 : by_channel2);
+    int l1 = c1 == 0 ? by_channel0 : (c1 == 1 ? by_channel1 : by_channel2);
+    int l2 = c2 == 0 ? by_channel0 : (c2 == 1 ? by_channel1 : by_channel2);
     uint32_t k = z ? kAcBytes : 0u;
     uint32_t shift = z ? kAcShift : kDcShift;
     uint32_t block = wt.block;
@@ -961,6 +985,9 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         stage_group(gw, ustream + ubase[img], ulen, first_sub);
     }
     __syncthreads();
+#if defined(JEA_PROBE_SYNC) && JEA_PROBE_SYNC == 1   // experiments (tools/probe_sync_steps.sh): the kernel up to here
+    return;
+#endif
     const uint32_t my_slot = (kRaw && owned) ? slot : tid;
 
     bool dirty = false;
@@ -991,6 +1018,9 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         __syncthreads();
         if (redo) ends[my_slot + 1] = my_end;
         if (!__syncthreads_or(redo ? 1 : 0)) break;
+#if defined(JEA_PROBE_SYNC) && JEA_PROBE_SYNC >= 2   // experiments: JEA_PROBE_SYNC - 1 walk steps
+        if (iteration + 2 == JEA_PROBE_SYNC) break;
+#endif
     }
 
     dirty = dirty && owned;

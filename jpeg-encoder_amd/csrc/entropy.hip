@@ -81,11 +81,6 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {   // a value that is
            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
 }
 
-// A barrier for threads that have exchanged data through LDS only.  __syncthreads() also orders global memory:
-// it waits for every store the wave has under way, and a loop that stores to memory and then meets a barrier
-// pays the stores' latency once per turn.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // The same scan with one barrier of the LDS-only kind; `lds4`: four words that the call before this one did not use
 // (two sets, taken in turn).
 __device__ __forceinline__ uint32_t block_exclusive_scan_256_lds(uint32_t v, uint32_t* lds4, uint32_t& total) {

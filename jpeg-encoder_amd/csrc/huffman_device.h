@@ -8,6 +8,11 @@
 
 namespace jea {
 
+// A barrier for threads that have exchanged data through LDS only.  __syncthreads() also orders global memory:
+// it waits for every load and store the wave has under way, so a loop that meets a barrier pays the latency of its
+// memory operations once per turn, and nothing asked for ahead of time stays ahead.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr uint32_t kStreamWin = 2048;  // bytes of compressed stream staged in LDS by the serial decoder
 
 struct HuffLds {
