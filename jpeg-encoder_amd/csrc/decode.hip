@@ -578,6 +578,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
     uint32_t shift = z ? kAcShift : kDcShift;
     int nb = 0, a0 = 0, a1 = 0, a2 = 0;
     BitWindow<GroupWords<W>> win(gw, p);
+#pragma unroll 2   // (two steps per turn: the values carried round the loop need no copies between them)
     while (p < end) {
         const uint32_t v = win.peek(p);
         const uint32_t e = step_lookup(tb + o0 + k, v, shift);
@@ -590,7 +591,7 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
         shift = done ? kDcShift : kAcShift;
-        a0 += ((int32_t)e < 0) ? step_amplitude(v, e) : 0;   // kStepDcAdd
+        if ((int32_t)e < 0) a0 += step_amplitude(v, e);      // kStepDcAdd (the sum inside the branch: no zero to add outside it)
         nb += done ? 1 : 0;
         const uint32_t o = o0;
         const int a = a0;
