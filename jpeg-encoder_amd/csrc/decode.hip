@@ -426,21 +426,23 @@ __device__ __forceinline__ RawGroup stage_group_raw(GroupWords<W, kTail>& gw, co
             const uint32_t t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
-        if (lane == 63) scratch[wave] = incl;
+        // one barrier a round: the waves' sums go to one of two sets of four words in turn (a set is written again two
+        // rounds on, behind the barrier of the round between)
+        uint32_t* const sums = scratch + ((p0 / kThreads) & 1u) * 4u;
+        if (lane == 63) sums[wave] = incl;
         lds_barrier();
         uint32_t before = carry + incl - kept;
-        for (int w = 0; w < wave; ++w) before += scratch[w];
-        const uint32_t round_total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        for (int w = 0; w < wave; ++w) before += sums[w];
+        const uint32_t round_total = sums[0] + sums[1] + sums[2] + sums[3];
         // stream bytes before the group's first raw byte, and up to the end of its raw range: both boundaries
-        // fall between pieces, and the warm-up pieces all lie in the first round
-        if (piece == warm_pieces) scratch[4] = before;
-        if (piece == warm_pieces + group_pieces) scratch[5] = before;
-        lds_barrier();
+        // fall between pieces; the warm-up pieces all lie in the first round, which needs the first figure at once
+        if (piece == warm_pieces) scratch[8] = before;
+        if (piece == warm_pieces + group_pieces) scratch[9] = before;
         if (p0 == 0) {
-            kept_warm = scratch[4];
+            lds_barrier();
+            kept_warm = scratch[8];
             shift = (int32_t)warm_bytes - (int32_t)kept_warm;
         }
-        if (warm_pieces + group_pieces >= p0 && warm_pieces + group_pieces < p0 + kThreads) kept_to_group_end = scratch[5];
         int32_t q = (int32_t)before + shift;
         if (plain && q >= 0 && (uint32_t)q + 16u <= G::kWords * 4u) {
             // words of the window are MSB first: the piece's bytes as four such words, shifted to where they start
@@ -467,8 +469,9 @@ __device__ __forceinline__ RawGroup stage_group_raw(GroupWords<W, kTail>& gw, co
             }
         }
         carry += round_total;
-        lds_barrier();
     }
+    lds_barrier();   // the second figure, and the window itself
+    kept_to_group_end = scratch[9];
     RawGroup rg;
     const uint64_t examined_end = raw0 + 16ull * pieces;
     rg.end_in_window = len <= examined_end;
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
     __shared__ StepTables t;
     __shared__ uint32_t ends[kThreads + 1];   // ends[i] = state at the start of the sub-sequence in slot i
     __shared__ Sums red[4];
-    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t scratch[12];
 
     const uint32_t tid = threadIdx.x;
     const bool from_args = kRaw && first_round && pro.n_words != 0;   // the scan ranges are kernel arguments
@@ -1225,7 +1228,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     __shared__ StepTables t;
     __shared__ Sums lds4[4];
     __shared__ __align__(8) uint32_t acc[kThreads * kAccWords];
-    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t scratch[12];
 
     const uint32_t tid = threadIdx.x;
     const GroupId gid = locate_group(gm, blockIdx.x, kGroupRaw, [&](uint32_t i) { return sizes[i]; });
