@@ -1867,7 +1867,7 @@ int jea_encode_host_batch(jea_ctx* ctx, const uint8_t* h_rgb, size_t n_images, u
                 if ((rc = ensure_host(ctx, sl.pin_out, sl.pin_out_bytes, bytes))) { result = rc; break; }
                 dst = (uint8_t*)sl.pin_out;
             }
-            JEA_HIP(ctx, hipMemcpyAsync(dst, sl.d_out.ptr, bytes, hipMemcpyDeviceToHost, ctx->copy_out));
+            if ((rc = copy_to_pinned(ctx, dst, sl.d_out.ptr, bytes, ctx->copy_out, bytes))) { result = rc; break; }
             JEA_HIP(ctx, hipEventRecord(sl.d2h, ctx->copy_out));
             placed[q & 1] = Placed{out_at, bytes};
             out_at = (out_at + bytes + 63) / 64 * 64;
