@@ -590,6 +590,10 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
         const uint32_t processed = z + ((e >> 8) & 0xffu);
         if (__builtin_expect(processed == 128u + 63u, 0)) p -= (e >> kStepEobLenShift) & 7u;   // see kernels.h: combined entries
         win.follow(p);
+#ifdef JEA_PROBE_WALK_PAD   // experiments: that many idle vector instructions a step -- is the walk bound by issue or by latency?
+#pragma unroll
+        for (int pad = 0; pad < JEA_PROBE_WALK_PAD; ++pad) asm volatile("v_mov_b32 %0, %0" : "+v"(nb));
+#endif
         const bool done = processed >= 63u;                  // end of block, or the block is full
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
