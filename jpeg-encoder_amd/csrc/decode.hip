@@ -886,6 +886,10 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
     __shared__ uint32_t ends[kThreads + 1];   // ends[i] = state at the start of the sub-sequence in slot i
     __shared__ Sums red[4];
     __shared__ uint32_t scratch[12];
+    __shared__ uint32_t wave_lanes[4];        // repair steps: lanes with work, by wave
+    __shared__ uint32_t work[kThreads];       // ... their slots, listed
+    __shared__ uint32_t res_end[kThreads];    // ... and what the walk of a listed slot gave
+    __shared__ Sums res_sums[kThreads];
 
     const uint32_t tid = threadIdx.x;
     const bool from_args = kRaw && first_round && pro.n_words != 0;   // the scan ranges are kernel arguments
@@ -1010,22 +1014,60 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         if (guess != kNoState) ends[my_slot + 1] = my_end;
         __syncthreads();
     }
+    // A repair step costs a wave the same whether one of its lanes walks or all of them, and from the third step on
+    // few do (those whose predecessor's end state changed once more).  So the lanes with work are counted, and where
+    // they would leave a wave's worth of lanes idle, their slots are listed and walked by the first lanes of the
+    // workgroup -- as few waves as it takes; the others wait at the barrier and leave their issue slots to the other
+    // workgroups of the compute unit.  Which wave comes first turns with the group and the step, so that the
+    // workgroups of a compute unit do not all pick the same SIMD.
+#ifndef JEA_COMPACT_BELOW
+#define JEA_COMPACT_BELOW 192
+#endif
+    constexpr uint32_t kCompactBelow = JEA_COMPACT_BELOW;
     uint32_t pending = 0;
     for (uint32_t iteration = 0;; ++iteration) {
         const uint32_t start = ends[my_slot];
         const bool redo = active && start != used;
+        const uint64_t votes = __ballot(redo ? 1 : 0);
+        if ((tid & 63u) == 0) wave_lanes[tid >> 6] = (uint32_t)__popcll(votes);
+        __syncthreads();   // every start state has been read, every count is there
+        const uint32_t n0 = wave_lanes[0], n1 = wave_lanes[1], n2 = wave_lanes[2], n3 = wave_lanes[3];
+        const uint32_t lanes = n0 + n1 + n2 + n3;
+        if (lanes == 0) break;
         if (iteration == kMaxLocalIterations) {   // the rest of the repair is left to the next launch
-            pending = __syncthreads_or(redo ? 1 : 0) ? 1u : 0u;
+            pending = 1;
             break;
         }
-        if (redo) {
-            my_end = walk<W>(gw, t, lum_mask, my_slot, start, sums, limit);
-            used = start;
-            dirty = true;
+        if (lanes >= kCompactBelow) {
+            if (redo) {
+                my_end = walk<W>(gw, t, lum_mask, my_slot, start, sums, limit);
+                used = start;
+                dirty = true;
+                ends[my_slot + 1] = my_end;
+            }
+        } else {
+            const uint32_t wave = tid >> 6;
+            const uint32_t before = (wave > 0 ? n0 : 0u) + (wave > 1 ? n1 : 0u) + (wave > 2 ? n2 : 0u);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
+            if (redo) work[before + rank] = my_slot;
+            __syncthreads();
+            const uint32_t turn = (tid + 64u * ((group + iteration) & 3u)) & (kThreads - 1u);
+            if (turn < lanes) {
+                const uint32_t its_slot = work[turn];
+                Sums its_sums;
+                res_end[its_slot] = walk<W>(gw, t, lum_mask, its_slot, ends[its_slot], its_sums, limit);
+                res_sums[its_slot] = its_sums;
+            }
+            __syncthreads();
+            if (redo) {
+                my_end = res_end[my_slot];
+                sums = res_sums[my_slot];
+                used = start;
+                dirty = true;
+                ends[my_slot + 1] = my_end;
+            }
         }
         __syncthreads();
-        if (redo) ends[my_slot + 1] = my_end;
-        if (!__syncthreads_or(redo ? 1 : 0)) break;
 #if defined(JEA_PROBE_SYNC) && JEA_PROBE_SYNC >= 2   // experiments: JEA_PROBE_SYNC - 1 walk steps
         if (iteration + 2 == JEA_PROBE_SYNC) break;
 #endif
