@@ -840,7 +840,13 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     wt.final_bit = final_bit;
 }
 
-constexpr uint32_t kMaxLocalIterations = 16;   // repair steps per launch; what is left is flagged pending
+#ifndef JEA_MAX_LOCAL_ITERATIONS
+#define JEA_MAX_LOCAL_ITERATIONS 24
+#endif
+#ifndef JEA_DENSE_EXTRA_ROUNDS
+#define JEA_DENSE_EXTRA_ROUNDS 2
+#endif
+constexpr uint32_t kMaxLocalIterations = JEA_MAX_LOCAL_ITERATIONS;   // repair steps per launch; what is left is flagged pending
 
 // What the kernels of the decoder that reads the raw scan need instead of the unstuffed copy.
 struct RawSource {
@@ -1741,8 +1747,7 @@ struct DecodeRun {
         // Dense streams synchronise late (see plan_entropy_decode): two more rounds of repair steps before the check.
         // A round in which nothing is left to repair costs its launch, some 10 us.
         if (p.dense) {
-            sync_round(0, sc.changed + 1, false);
-            sync_round(0, sc.changed + 1, false);
+            for (int extra = 0; extra < JEA_DENSE_EXTRA_ROUNDS; ++extra) sync_round(0, sc.changed + 1, false);
         }
         if (sc.marks != nullptr) (void)hipEventRecord(sc.marks[1], s);
         scan_and_write(sc.changed + 2);
