@@ -566,7 +566,9 @@ __device__ __forceinline__ uint32_t next_channel(uint32_t c) { return c == 2u ? 
 // The loop body has no branches.  What depends on the channel -- table class, DC sum -- is kept in
 // three registers each, rotated when a block ends, so that the current channel's is always the first.
 // `limit`: the sub-sequence ends there at the latest (the end of a group that holds a short last sub-sequence).
-template <uint32_t W>
+// kSums = false: the end state and the block count only (the DC sums come back zero): a quarter fewer instructions a
+// step, for the repair steps of streams that take many of them (see decode_sync_kernel).
+template <uint32_t W, bool kSums = true>
 __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTables& t, uint32_t lum_mask,
                                          uint32_t sub, uint32_t state, Sums& sums, uint32_t limit = 0xffffffffu) {
     constexpr uint32_t kSubBits = 32 * W;
@@ -598,12 +600,12 @@ __device__ __forceinline__ uint32_t walk(const GroupWords<W>& gw, const StepTabl
         z = done ? 0u : processed + 1u;
         k = done ? 0u : kAcBytes;
         shift = done ? kDcShift : kAcShift;
-        if ((int32_t)e < 0) a0 += step_amplitude(v, e);      // kStepDcAdd (the sum inside the branch: no zero to add outside it)
+        if (kSums && (int32_t)e < 0) a0 += step_amplitude(v, e);   // kStepDcAdd (the sum inside the branch: no zero to add outside it)
         nb += done ? 1 : 0;
         const uint32_t o = o0;
         const int a = a0;
         o0 = done ? o1 : o0; o1 = done ? o2 : o1; o2 = done ? o : o2;
-        a0 = done ? a1 : a0; a1 = done ? a2 : a1; a2 = done ? a : a2;
+        if (kSums) { a0 = done ? a1 : a0; a1 = done ? a2 : a1; a2 = done ? a : a2; }
     }
     // (a0, a1, a2) belong to the channel the walk ended in and the two after it
     const uint32_t turns = (uint32_t)nb % 3u;
@@ -840,6 +842,7 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
     wt.final_bit = final_bit;
 }
 
+constexpr int kSumsMissing = 0x40000000;   // in a record's block count: its DC sums are still to be computed (decode_sync_kernel)
 #ifndef JEA_MAX_LOCAL_ITERATIONS
 #define JEA_MAX_LOCAL_ITERATIONS 24
 #endif
@@ -946,6 +949,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
 
     uint32_t used = kNoState, my_end = 0, guess = kNoState;
     Sums sums{0, 0, 0, 0};
+    bool sums_missing = false, carried = false;
     if (!first_round) {
         // Unless the previous launch ran out of repair steps, it left the group consistent in itself,
         // and only the first owned sub-sequence can have a new start state: the end state of the
@@ -971,10 +975,12 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
             need = need || (active && entry != used) || grp_pending[group_index] != 0;
         }
         if (!__syncthreads_or(need ? 1 : 0)) return;
+        carried = grp_pending[group_index] != 0;
         if (owned) {
             my_end = sub_end[sub_index];
             const int4 si = sub_info[sub_index];
-            sums = Sums{si.x, si.y, si.z, si.w};
+            sums_missing = (si.x & kSumsMissing) != 0;   // left by a launch that ran out of steps
+            sums = Sums{si.x & ~kSumsMissing, si.y, si.z, si.w};
         }
         if (kRaw) {
             if (tid == kWarm) ends[warm_slots] = entry;
@@ -1013,6 +1019,7 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         // offered start states first; the loop below keeps them only where they fit their predecessors
         if (guess != kNoState) {
             my_end = walk<W>(gw, t, lum_mask, my_slot, guess, sums, limit);
+            sums_missing = false;
             used = guess;
             dirty = true;
         }
@@ -1030,6 +1037,19 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
 #define JEA_COMPACT_BELOW 192
 #endif
     constexpr uint32_t kCompactBelow = JEA_COMPACT_BELOW;
+    // A stream whose listed lanes are still at it after a few steps is one whose wrong start states travel far (noise:
+    // through dozens of sub-sequences, one a step).  From then on the listed walks leave the DC sums out -- a quarter
+    // of a step's instructions -- and the lanes whose last walk was of that kind walk once more, in full, when the
+    // group has settled.  A launch that runs out of steps leaves that walk to the next one: it marks the records
+    // (kSumsMissing), and the next launch starts with the light walks at once.  Only where the launch leaves
+    // workgroup slots free, though (four a compute unit): there a step costs its latency whatever its width, and the
+    // full walk at the end costs one step; on a full GPU a listed step costs a quarter of that walk's issue slots,
+    // and a stream would have to take dozens of steps (those that run out of them do) for the exchange to pay.
+#ifndef JEA_LIGHT_FROM
+#define JEA_LIGHT_FROM 4
+#endif
+    constexpr uint32_t kLightFrom = JEA_LIGHT_FROM;
+    const bool roomy = gridDim.x <= 1024u;
     uint32_t pending = 0;
     for (uint32_t iteration = 0;; ++iteration) {
         const uint32_t start = ends[my_slot];
@@ -1047,11 +1067,13 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         if (lanes >= kCompactBelow) {
             if (redo) {
                 my_end = walk<W>(gw, t, lum_mask, my_slot, start, sums, limit);
+                sums_missing = false;
                 used = start;
                 dirty = true;
                 ends[my_slot + 1] = my_end;
             }
         } else {
+            const bool light = carried || (roomy && iteration >= kLightFrom);
             const uint32_t wave = tid >> 6;
             const uint32_t before = (wave > 0 ? n0 : 0u) + (wave > 1 ? n1 : 0u) + (wave > 2 ? n2 : 0u);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
@@ -1061,13 +1083,15 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
             if (turn < lanes) {
                 const uint32_t its_slot = work[turn];
                 Sums its_sums;
-                res_end[its_slot] = walk<W>(gw, t, lum_mask, its_slot, ends[its_slot], its_sums, limit);
+                if (light) res_end[its_slot] = walk<W, false>(gw, t, lum_mask, its_slot, ends[its_slot], its_sums, limit);
+                else res_end[its_slot] = walk<W>(gw, t, lum_mask, its_slot, ends[its_slot], its_sums, limit);
                 res_sums[its_slot] = its_sums;
             }
             __syncthreads();
             if (redo) {
                 my_end = res_end[my_slot];
                 sums = res_sums[my_slot];
+                sums_missing = light;
                 used = start;
                 dirty = true;
                 ends[my_slot + 1] = my_end;
@@ -1079,12 +1103,17 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
 #endif
     }
 
+    if (sums_missing && owned && !pending) {
+        (void)walk<W>(gw, t, lum_mask, my_slot, used, sums, limit);
+        sums_missing = false;
+        dirty = true;
+    }
     dirty = dirty && owned;
     const int any_dirty = __syncthreads_or(dirty ? 1 : 0);
     if (dirty) {
         __atomic_store_n(&sub_end[sub_index], my_end, __ATOMIC_RELAXED);
         sub_used[sub_index] = used;
-        sub_info[sub_index] = make_int4(sums.nb, sums.dc0, sums.dc1, sums.dc2);
+        sub_info[sub_index] = make_int4(sums.nb | (sums_missing ? kSumsMissing : 0), sums.dc0, sums.dc1, sums.dc2);
         if (kRaw && (tid - kWarm) + 1 == n_active) __atomic_store_n(&raw.grp_end[group_index], my_end, __ATOMIC_RELAXED);
     } else if (first_round && owned) {   // sub-sequences past the end of the stream
         sub_end[sub_index] = 0;
@@ -1352,7 +1381,7 @@ __global__ __launch_bounds__(kThreads) void decode_write_kernel(const uint8_t* _
     for (uint32_t i = 0; i < kAccWords; ++i) acc[tid * kAccWords + i] = 0;
 
     Sums total;
-    const Sums before = block_exclusive_scan(Sums{si.x, si.y, si.z, si.w}, lds4, total);   // also orders the staging
+    const Sums before = block_exclusive_scan(Sums{si.x & ~kSumsMissing, si.y, si.z, si.w}, lds4, total);   // also orders the staging
     WriteTarget wt;
     wt.out = coefs + (size_t)img * total_blocks * 64;
     wt.records = kPlanar ? records + (size_t)img * total_blocks : nullptr;

@@ -435,6 +435,29 @@ def test_decode_uneven_batch_with_a_stream_beyond_the_folded_scan(ctx, po, jea):
         assert np.array_equal(got[i], po.decode(f, w, h, quality)), i
 
 
+@pytest.mark.parametrize("w,h,quality,copies", [(1024, 1024, 90, 1), (1024, 1024, 95, 1), (512, 512, 95, 3), (1920, 1080, 50, 2)])
+def test_decode_noise_that_synchronises_late(ctx, po, jea, w, h, quality, copies):
+    """Noise has no end-of-block codes, so a wrong start state travels through dozens of sub-sequences before it
+    falls into step: the synchronisation takes many repair steps, in more than one launch at the higher qualities
+    (steps with few lanes at work are listed and walked without the DC sums, which a last walk supplies; a launch
+    that runs out of steps hands that walk on to the next)."""
+    lum, chrom = jea.binding.quant_tables(quality)
+    files = [po.encode(po.gen_image(w, h, 1, 300 + i), quality) for i in range(copies)]
+    offsets, sizes, blob = [], [], b""
+    for f in files:
+        offsets.append(len(blob)); sizes.append(len(f))
+        blob += f + b"\0" * (-len(f) % 64)
+    got = ctx.decode_batch(ctx.to_device(np.frombuffer(blob, np.uint8)), offsets, sizes, w, h, lum,
+                           chrom).cpu().numpy().reshape(copies, h, w, 3)
+    for i, f in enumerate(files):
+        assert np.array_equal(got[i], po.decode(f, w, h, quality)), i
+    m = jea.binding.n_mcu(w, h)
+    coefs = ctx.entropy_decode(ctx.to_device(np.frombuffer(blob, np.uint8)), [o + 607 for o in offsets],
+                               [s - 607 for s in sizes], m).cpu().numpy().reshape(copies, m * 3, 64)
+    for i, f in enumerate(files):
+        assert np.array_equal(coefs[i], po.scan_to_coefs(f[607:], m)[0].reshape(m * 3, 64)), i
+
+
 def test_decode_periodic_streams(ctx, po, jea):
     """Flat and regularly patterned pictures give streams with a short period, in which a decoder that starts
     in a wrong state can stay out of phase for ever: the decoder's synchronisation then has to travel from
