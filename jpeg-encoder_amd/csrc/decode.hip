@@ -1048,12 +1048,20 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
 #ifndef JEA_LIGHT_FROM
 #define JEA_LIGHT_FROM 4
 #endif
+#ifndef JEA_OPENING_LIGHT
+#define JEA_OPENING_LIGHT 1
+#endif
     constexpr uint32_t kLightFrom = JEA_LIGHT_FROM;
     const bool roomy = gridDim.x <= 1024u;
+    // The opening step of the first round walks every sub-sequence from a guess that is all but never right, so all
+    // of it is walked again in the second step anyway: the opening walks leave the sums out too, and what they walked
+    // is walked again whether or not its start state changed (`unsummed`).
+    bool unsummed = false;
     uint32_t pending = 0;
     for (uint32_t iteration = 0;; ++iteration) {
         const uint32_t start = ends[my_slot];
-        const bool redo = active && start != used;
+        const bool redo = active && (start != used || unsummed);
+        const bool opening = JEA_OPENING_LIGHT && first_round && iteration == 0;
         const uint64_t votes = __ballot(redo ? 1 : 0);
         if ((tid & 63u) == 0) wave_lanes[tid >> 6] = (uint32_t)__popcll(votes);
         __syncthreads();   // every start state has been read, every count is there
@@ -1066,14 +1074,16 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
         }
         if (lanes >= kCompactBelow) {
             if (redo) {
-                my_end = walk<W>(gw, t, lum_mask, my_slot, start, sums, limit);
+                if (opening) my_end = walk<W, false>(gw, t, lum_mask, my_slot, start, sums, limit);
+                else my_end = walk<W>(gw, t, lum_mask, my_slot, start, sums, limit);
+                unsummed = opening;
                 sums_missing = false;
                 used = start;
                 dirty = true;
                 ends[my_slot + 1] = my_end;
             }
         } else {
-            const bool light = carried || (roomy && iteration >= kLightFrom);
+            const bool light = opening || carried || (roomy && iteration >= kLightFrom);
             const uint32_t wave = tid >> 6;
             const uint32_t before = (wave > 0 ? n0 : 0u) + (wave > 1 ? n1 : 0u) + (wave > 2 ? n2 : 0u);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
@@ -1091,7 +1101,8 @@ __global__ __launch_bounds__(kThreads) void decode_sync_kernel(const uint8_t* __
             if (redo) {
                 my_end = res_end[my_slot];
                 sums = res_sums[my_slot];
-                sums_missing = light;
+                sums_missing = light && !opening;
+                unsummed = opening;
                 used = start;
                 dirty = true;
                 ends[my_slot + 1] = my_end;
