@@ -803,6 +803,10 @@ __device__ __forceinline__ void write_blocks(const GroupWords<W, kWriteTail>& gw
         const uint32_t processed = z + ((e >> 8) & 0xffu);
         if (__builtin_expect(processed == 128u + 63u, 0)) p -= (e >> kStepEobLenShift) & 7u;   // see kernels.h: combined entries
         win.follow(p);
+#ifdef JEA_PROBE_WRITE_PAD   // experiments: that many idle vector instructions a step -- what is an instruction worth here?
+#pragma unroll
+        for (int pad = 0; pad < JEA_PROBE_WRITE_PAD; ++pad) asm volatile("v_mov_b32 %0, %0" : "+v"(trouble));
+#endif
         const bool done = processed >= 63u;
         const uint32_t position = processed & 0x7fu;
         z = done ? 0u : processed + 1u;
