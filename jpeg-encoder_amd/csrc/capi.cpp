@@ -1410,7 +1410,7 @@ static int run_entropy_decode(jea_ctx* ctx, const uint8_t* d_data, const uint64_
     // Every image gets the workgroups its own scan needs; with many images the kernels look their image up in a
     // table, which travels with the scan ranges.
     const DecodePlan plan = plan_entropy_decode(n_images, scan_sizes.data(), max_size, mcus, total_size);
-    if ((uint64_t)plan.total_groups * 240ull > 0x7fffffffull)
+    if ((uint64_t)plan.total_subs > 0x7fffffffull)
         return fail(ctx, JEA_ERR_INVALID_ARG, "decode: streams too large for one call");
     // host to device: offsets | sizes | unstuffed bases | first workgroup of every image | (image, group) per workgroup
     const size_t seg_bytes = 3 * n_images * sizeof(uint64_t);

@@ -61,7 +61,12 @@ constexpr uint32_t kSubWordsSmall = 2, kSubWordsMedium = 4, kSubWordsLarge = 16;
 // A workgroup owns kOwned consecutive sub-sequences.  In the first round its first kWarm threads
 // decode the last sub-sequences of the previous workgroup once more, only to hand the first owned
 // sub-sequence a start state that has most likely synchronised already.
-constexpr uint32_t kWarm = 16;
+// (8: with 16 the sync rounds and the write pass of detailed and noisy batches took 3-8 % longer -- a sixteenth of the
+// lanes own nothing --, with 4 a 4K picture of noise needs a quarter more repair steps)
+#ifndef JEA_WARM_SLOTS
+#define JEA_WARM_SLOTS 8
+#endif
+constexpr uint32_t kWarm = JEA_WARM_SLOTS;
 constexpr uint32_t kOwned = kThreads - kWarm;
 
 // Which image a workgroup belongs to and which of that image's groups it is.  A job's workgroups are numbered

@@ -219,7 +219,7 @@ def test_decode_batch_whose_block_records_leave_in_fours_at_every_alignment(ctx,
         sources.append(img)
     files = [po.encode(sx, q) for sx in sources]
     total = sum(len(files[i % 4]) - 607 for i in range(n))
-    assert total >= 256 * 240 * 4 * 16 and total * 8 < 40 * 459 * n, total      # the condition for records in fours
+    assert total >= 256 * 248 * 4 * 16 and total * 8 < 40 * 459 * n, total      # the condition for records in fours
     want = [torch.from_numpy(po.decode(f, w, h, q).copy()).to(ctx.tdev) for f in files]
     kind = (np.arange(n) * 7 // 3) % 4
     sizes = np.array([len(files[k]) for k in kind], dtype=np.uint64)

@@ -425,7 +425,7 @@ def test_decode_uneven_batch_with_a_stream_beyond_the_folded_scan(ctx, po, jea):
     lum, chrom = jea.binding.quant_tables(quality)
     pictures = [po.gen_image(w, h, 0, 41), po.gen_image(w, h, 1, 42), po.gen_image(w, h, 0, 43)]
     files = [po.encode(im, quality) for im in pictures]
-    assert len(files[1]) > 1024 * 15360
+    assert len(files[1]) > 1024 * 15872
     offsets, sizes, blob = [], [], b""
     for f in files:
         offsets.append(len(blob)); sizes.append(len(f))
